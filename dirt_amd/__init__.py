@@ -1,0 +1,4 @@
+"""dirt_amd -- MI355X-native drop-in for the hot path of pmh47/dirt:
+`rasterise`, `rasterise_batch`, `rasterise_deferred`, `rasterise_batch_deferred` (dirt/__init__.py:2)."""
+from .rasterise_ops import rasterise, rasterise_batch, rasterise_deferred, rasterise_batch_deferred  # noqa: F401
+from . import rasterise_ops  # noqa: F401

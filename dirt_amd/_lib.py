@@ -1,0 +1,77 @@
+"""ctypes binding of libdirt_hip.so (the C ABI declared in include/dirt_hip.h).
+
+This is the counterpart of `tf.load_op_library(.../librasterise.so)` in the reference
+(dirt/rasterise_ops.py:5-10).  Unlike the reference, which swallows a load failure with a warning and
+leaves `_rasterise_module = None`, a missing or unloadable library raises as soon as an op is used:
+there is no CPU or eager fallback behind these entry points.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdirt_hip.so')
+ABI_VERSION = 1
+
+FLAG_Q1_INTENDED = 1
+
+E_INVALID_ARGUMENT = -1
+E_TOO_MANY_VERTICES = -2
+E_WORKSPACE = -3
+E_HIP = -4
+
+_lib = None
+
+# every symbol include/dirt_hip.h declares (tests/test_boundary.py checks header <-> library)
+SYMBOLS = ('dirt_abi_version', 'dirt_last_error', 'dirt_workspace_bytes', 'dirt_rasterise_forward',
+           'dirt_rasterise_backward', 'dirt_rasterise_visibility')
+
+
+class DirtLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libdirt_hip.so and declare the prototypes.  Raises DirtLibraryError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DirtLibraryError(
+            'libdirt_hip.so is missing (%s): build it with `python -m dirt_amd.build` (hipcc, gfx950). '
+            'dirt_amd has no fallback path.' % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise DirtLibraryError('failed to load %s: %s' % (LIB_PATH, e))
+    vp, fp, ip = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p  # raw device addresses
+    i, sz, u = ctypes.c_int, ctypes.c_size_t, ctypes.c_uint
+    lib.dirt_abi_version.restype = i
+    lib.dirt_last_error.restype = ctypes.c_char_p
+    lib.dirt_workspace_bytes.argtypes = [i] * 6
+    lib.dirt_workspace_bytes.restype = sz
+    lib.dirt_rasterise_forward.argtypes = [fp, fp, fp, ip, fp, i, i, i, i, i, i, vp, sz, u, vp]
+    lib.dirt_rasterise_forward.restype = i
+    lib.dirt_rasterise_backward.argtypes = [fp, ip, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, vp, sz, u, vp]
+    lib.dirt_rasterise_backward.restype = i
+    lib.dirt_rasterise_visibility.argtypes = [fp, ip, ip, i, i, i, i, i, vp, sz, u, vp]
+    lib.dirt_rasterise_visibility.restype = i
+    if lib.dirt_abi_version() != ABI_VERSION:
+        raise DirtLibraryError('libdirt_hip.so ABI %d != expected %d' % (lib.dirt_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().dirt_last_error().decode('utf-8', 'replace')
+
+
+def check(rc):
+    """Map a C-ABI return code to the exception the reference raises for the same condition:
+    errors::InvalidArgument -> ValueError (csrc/rasterise_egl.cpp:302-316); HIP failures, which the
+    reference turns into LOG(FATAL), -> RuntimeError."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc in (E_INVALID_ARGUMENT, E_TOO_MANY_VERTICES, E_WORKSPACE):
+        raise ValueError(msg)
+    raise RuntimeError(msg)

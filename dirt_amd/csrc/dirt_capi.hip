@@ -1,0 +1,199 @@
+// dirt_capi.hip -- the C ABI of libdirt_hip.so (see include/dirt_hip.h for the contract and the
+// reference interfaces each entry point replaces).  Host code only: argument validation with the
+// reference's error conditions, workspace carving, and kernel launches on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "../../include/dirt_hip.h"
+#include "dirt_launch.h"
+
+namespace {
+
+thread_local char g_last_error[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Workspace {
+    size_t recs_off, boxes_off, vis_off, total;
+};
+
+// Layout: [FaceRec x B*F | FaceBox x B*F | int32 visibility x B*H*W]
+Workspace carve(int B, int F, int H, int W)
+{
+    Workspace w;
+    size_t off = 0;
+    w.recs_off = off;  off = align_up(off + (size_t)B * F * sizeof(dirt::FaceRec), 256);
+    w.boxes_off = off; off = align_up(off + (size_t)B * F * sizeof(dirt::FaceBox), 256);
+    w.vis_off = off;   off = align_up(off + (size_t)B * H * W * sizeof(int32_t), 256);
+    w.total = off + 256;
+    return w;
+}
+
+int check_sizes(const char* who, int B, int V, int F, int H, int W, int C)
+{
+    if (B < 0 || V < 0 || F < 0)
+        return fail(DIRT_E_INVALID_ARGUMENT, "%s: negative batch / vertex / face count (B=%d V=%d F=%d)", who, B, V, F);
+    if (H <= 0 || W <= 0)  // CHECK(width > 0 && height > 0), csrc/hwc.h:28
+        return fail(DIRT_E_INVALID_ARGUMENT, "%s: height and width must be positive (H=%d W=%d)", who, H, W);
+    if (C <= 0)  // the reference op requires C in {1,3} (csrc/hwc.h:27); its Python layer accepts C > 0
+        return fail(DIRT_E_INVALID_ARGUMENT, "%s: channels must be positive (C=%d)", who, C);
+    if (H > DIRT_MAX_DIM || W > DIRT_MAX_DIM)
+        return fail(DIRT_E_INVALID_ARGUMENT, "%s: frame larger than %d pixels (H=%d W=%d)", who, DIRT_MAX_DIM, H, W);
+    if (B > 65535) return fail(DIRT_E_INVALID_ARGUMENT, "%s: batch larger than 65535 (B=%d)", who, B);
+    return DIRT_OK;
+}
+
+int check_workspace(const char* who, const Workspace& w, void* workspace, size_t bytes)
+{
+    if (!workspace) return fail(DIRT_E_WORKSPACE, "%s: workspace is NULL", who);
+    if (((uintptr_t)workspace & 15u) != 0) return fail(DIRT_E_WORKSPACE, "%s: workspace is not 16-byte aligned", who);
+    if (bytes < w.total)
+        return fail(DIRT_E_WORKSPACE, "%s: workspace too small (%zu bytes given, %zu needed)", who, bytes, w.total);
+    return DIRT_OK;
+}
+
+#define HIP_TRY(who, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(DIRT_E_HIP, "%s: %s failed: %s", who, #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+inline char* base256(void* workspace)
+{
+    // FaceRec needs 128-byte alignment; the caller guarantees 16.
+    return reinterpret_cast<char*>(align_up((size_t)(uintptr_t)workspace, 256));
+}
+
+}  // namespace
+
+extern "C" {
+
+int dirt_abi_version(void) { return DIRT_ABI_VERSION; }
+
+const char* dirt_last_error(void) { return g_last_error; }
+
+size_t dirt_workspace_bytes(int B, int V, int F, int H, int W, int C)
+{
+    if (check_sizes("dirt_workspace_bytes", B, V, F, H, W, C) != DIRT_OK) return 0;
+    return carve(B, F, H, W).total;
+}
+
+int dirt_rasterise_forward(const float* background, const float* vertices, const float* vertex_colors,
+                           const int32_t* faces, float* pixels, int B, int V, int F, int H, int W, int C,
+                           void* workspace, size_t workspace_bytes, unsigned flags, void* stream_)
+{
+    const char* who = "dirt_rasterise_forward";
+    (void)flags;
+    int rc = check_sizes(who, B, V, F, H, W, C);
+    if (rc) return rc;
+    if (B == 0) return DIRT_OK;
+    if (!background || !pixels) return fail(DIRT_E_INVALID_ARGUMENT, "%s: background / pixels is NULL", who);
+    if ((V > 0 && (!vertices || !vertex_colors)) || (F > 0 && !faces))
+        return fail(DIRT_E_INVALID_ARGUMENT, "%s: vertices / vertex_colors / faces is NULL", who);
+    const Workspace w = carve(B, F, H, W);
+    rc = check_workspace(who, w, workspace, workspace_bytes);
+    if (rc) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    char* ws = base256(workspace);
+    auto* recs = reinterpret_cast<dirt::FaceRec*>(ws + w.recs_off);
+    auto* boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
+
+    HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+    dirt::RasterParams p;
+    p.recs = recs; p.boxes = boxes; p.background = background; p.vertex_colors = vertex_colors;
+    p.pixels = pixels; p.vis = nullptr;
+    p.V = V; p.F = F; p.H = H; p.W = W; p.C = C;
+    p.tiles_x = (W + 31) / 32; p.tiles_y = (H + 31) / 32;
+    HIP_TRY(who, dirt::launch_raster(p, B, false, stream));
+    g_last_error[0] = 0;
+    return DIRT_OK;
+}
+
+int dirt_rasterise_visibility(const float* vertices, const int32_t* faces, int32_t* face_id, int B, int V, int F,
+                              int H, int W, void* workspace, size_t workspace_bytes, unsigned flags, void* stream_)
+{
+    const char* who = "dirt_rasterise_visibility";
+    (void)flags;
+    int rc = check_sizes(who, B, V, F, H, W, 1);
+    if (rc) return rc;
+    if (B == 0) return DIRT_OK;
+    if (!face_id) return fail(DIRT_E_INVALID_ARGUMENT, "%s: face_id is NULL", who);
+    if ((V > 0 && !vertices) || (F > 0 && !faces))
+        return fail(DIRT_E_INVALID_ARGUMENT, "%s: vertices / faces is NULL", who);
+    const Workspace w = carve(B, F, H, W);
+    rc = check_workspace(who, w, workspace, workspace_bytes);
+    if (rc) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    char* ws = base256(workspace);
+    auto* recs = reinterpret_cast<dirt::FaceRec*>(ws + w.recs_off);
+    auto* boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
+    HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+    dirt::RasterParams p;
+    p.recs = recs; p.boxes = boxes; p.background = nullptr; p.vertex_colors = nullptr;
+    p.pixels = nullptr; p.vis = face_id;
+    p.V = V; p.F = F; p.H = H; p.W = W; p.C = 1;
+    p.tiles_x = (W + 31) / 32; p.tiles_y = (H + 31) / 32;
+    HIP_TRY(who, dirt::launch_raster(p, B, true, stream));
+    g_last_error[0] = 0;
+    return DIRT_OK;
+}
+
+int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const float* pixels,
+                            const float* grad_pixels, float* grad_background, float* grad_vertices,
+                            float* grad_vertex_colors, float* debug_thingy, int B, int V, int F, int H, int W, int C,
+                            void* workspace, size_t workspace_bytes, unsigned flags, void* stream_)
+{
+    const char* who = "dirt_rasterise_backward";
+    int rc = check_sizes(who, B, V, F, H, W, C);
+    if (rc) return rc;
+    if (V > (1 << 24))  // csrc/rasterise_grad_egl.cpp:399-405
+        return fail(DIRT_E_TOO_MANY_VERTICES, "%s: supports a maximum of %d vertices, vs. %d passed", who, 1 << 24, V);
+    if (B == 0) return DIRT_OK;
+    if (!pixels || !grad_pixels || !grad_background)
+        return fail(DIRT_E_INVALID_ARGUMENT, "%s: pixels / grad_pixels / grad_background is NULL", who);
+    if ((V > 0 && (!vertices || !grad_vertices || !grad_vertex_colors)) || (F > 0 && !faces))
+        return fail(DIRT_E_INVALID_ARGUMENT, "%s: vertices / faces / grad_vertices / grad_vertex_colors is NULL", who);
+    const Workspace w = carve(B, F, H, W);
+    rc = check_workspace(who, w, workspace, workspace_bytes);
+    if (rc) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    char* ws = base256(workspace);
+    auto* recs = reinterpret_cast<dirt::FaceRec*>(ws + w.recs_off);
+    auto* boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
+    auto* vis = reinterpret_cast<int32_t*>(ws + w.vis_off);
+
+    // cudaMemsetAsync x4, csrc/rasterise_grad_egl.cu:244-250 (grad_background and debug_thingy are
+    // fully written by the kernel instead)
+    if (V > 0) {
+        HIP_TRY(who, hipMemsetAsync(grad_vertices, 0, sizeof(float) * (size_t)B * V * 4, stream));
+        HIP_TRY(who, hipMemsetAsync(grad_vertex_colors, 0, sizeof(float) * (size_t)B * V * C, stream));
+    }
+    HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+    dirt::RasterParams rp;
+    rp.recs = recs; rp.boxes = boxes; rp.background = nullptr; rp.vertex_colors = nullptr;
+    rp.pixels = nullptr; rp.vis = vis;
+    rp.V = V; rp.F = F; rp.H = H; rp.W = W; rp.C = C;
+    rp.tiles_x = (W + 31) / 32; rp.tiles_y = (H + 31) / 32;
+    HIP_TRY(who, dirt::launch_raster(rp, B, true, stream));
+
+    dirt::GradParams gp;
+    gp.recs = recs; gp.vis = vis; gp.vertices = vertices; gp.pixels = pixels; gp.grad_pixels = grad_pixels;
+    gp.grad_background = grad_background; gp.grad_vertices = grad_vertices;
+    gp.grad_vertex_colors = grad_vertex_colors; gp.debug_thingy = debug_thingy;
+    gp.B = B; gp.V = V; gp.F = F; gp.H = H; gp.W = W; gp.C = C; gp.flags = flags;
+    HIP_TRY(who, dirt::launch_grad(gp, stream));
+    g_last_error[0] = 0;
+    return DIRT_OK;
+}
+
+}  // extern "C"

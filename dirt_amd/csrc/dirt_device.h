@@ -1,0 +1,144 @@
+// dirt_device.h -- device-side data layout and per-sample arithmetic shared by the gfx950 kernels.
+//
+// The arithmetic follows the numeric specification in DESIGN.md ("Numeric specification"), which
+// the CPU oracle (oracle/dirt_oracle.c) restates independently: every step is an IEEE-754 basic
+// operation evaluated in the written order (the library is built with -ffp-contract=off), so the
+// two agree bit for bit on coverage, depth and interpolated colour.
+//
+// Reference semantics being replaced (paths relative to the reference repository):
+//   triangle set-up / coverage / depth / interpolation : the GL pipeline driven by
+//       csrc/rasterise_egl.cpp:362-380 and csrc/rasterise_grad_egl.cpp:432-456 with the shaders of
+//       csrc/shaders.cpp:16-79;
+//   vertex expansion                                   : upload_vertices, csrc/rasterise_grad_egl.cu:12-34.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dirt {
+
+// One set-up triangle, 128 bytes, 128-byte aligned so a record is one L2 line and can be fetched
+// with two wide scalar loads.  The first 100 bytes are what the coverage / depth loop needs.
+//
+// Sign folding: for an edge whose on-edge samples are EXCLUDED by the tie rule the three
+// coefficients and zs are stored negated (F_k = -E_k).  The coverage test then is a single
+// `F_k >= 0` compare per edge, xor-ed with the edge's `excl` flag; products F_k*zs_k are unchanged
+// by the double negation, so depth is bit-identical to the unfolded form.
+struct alignas(128) FaceRec {
+    double coef[9];   //   0: (a,b,c) of edges 0,1,2, sign-folded
+    double zs[3];     //  72: clip z_k * inv_det, sign-folded
+    uint32_t flags;   //  96: bit k = edge k folded (exclusive); bit 31 = valid
+    uint32_t pad0;    // 100
+    double inv_det;   // 104: 1/|det|
+    int32_t vid[3];   // 112: vertex indices of the face
+    uint32_t pad1;    // 124
+};
+static_assert(sizeof(FaceRec) == 128, "FaceRec must be 128 bytes");
+
+constexpr uint32_t FACE_VALID = 0x80000000u;
+
+// Conservative pixel bounding box in tensor orientation (columns i, rows r, inclusive).
+// A culled face has an empty box (i_min > i_max) that overlaps nothing.
+struct alignas(8) FaceBox {
+    int16_t i_min, i_max, r_min, r_max;
+};
+static_assert(sizeof(FaceBox) == 8, "FaceBox must be 8 bytes");
+
+constexpr uint32_t Z24_CLEAR = 0x00FFFFFFu;  // glClear(GL_DEPTH_BUFFER_BIT) to 1.0 in a D24 buffer
+
+// ---------------------------------------------------------------------------------------------
+// Triangle set-up for one face (the GL primitive assembly + viewport transform).
+// Returns false when the face is dropped (bad index, non-finite data, zero area, behind the eye,
+// outside the depth range as a whole, or covering no pixel centre).
+__device__ inline bool setup_face(const float* __restrict__ verts, int V, const int32_t* __restrict__ face,
+                                  int H, int W, FaceRec& rec, FaceBox& box)
+{
+    double X[3], Y[3], Wc[3], Z[3];
+    for (int k = 0; k < 3; ++k) {
+        const int32_t vi = face[k];
+        if (vi < 0 || vi >= V) return false;
+        const float4 v = *reinterpret_cast<const float4*>(verts + (size_t)vi * 4);
+        if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w))) return false;
+        X[k] = ((double)v.x + (double)v.w) * (0.5 * (double)W);
+        Y[k] = ((double)v.y + (double)v.w) * (0.5 * (double)H);
+        Wc[k] = (double)v.w;
+        Z[k] = (double)v.z;
+        rec.vid[k] = vi;
+    }
+    double a[3], b[3], c[3];
+    for (int k = 0; k < 3; ++k) {
+        const int p = (k + 1) % 3, q = (k + 2) % 3;
+        double m1, m2;
+        m1 = Y[p] * Wc[q]; m2 = Wc[p] * Y[q]; a[k] = m1 - m2;
+        m1 = Wc[p] * X[q]; m2 = X[p] * Wc[q]; b[k] = m1 - m2;
+        m1 = X[p] * Y[q];  m2 = Y[p] * X[q];  c[k] = m1 - m2;
+    }
+    const double t0 = X[0] * a[0], t1 = Y[0] * b[0], t2 = Wc[0] * c[0];
+    double det = (t0 + t1) + t2;
+    if (!isfinite(det) || det == 0.0) return false;
+    if (det < 0.0) {
+        for (int k = 0; k < 3; ++k) { a[k] = -a[k]; b[k] = -b[k]; c[k] = -c[k]; }
+        det = -det;
+    }
+    const double inv_det = 1.0 / det;
+    if (!isfinite(inv_det)) return false;
+
+    const int npos = (Wc[0] > 0.0) + (Wc[1] > 0.0) + (Wc[2] > 0.0);
+    if (npos == 0) return false;
+    int i_min = 0, i_max = W - 1, j_min = 0, j_max = H - 1;
+    if (npos == 3) {
+        if (Z[0] > Wc[0] && Z[1] > Wc[1] && Z[2] > Wc[2]) return false;
+        if (Z[0] < -Wc[0] && Z[1] < -Wc[1] && Z[2] < -Wc[2]) return false;
+        double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        for (int k = 0; k < 3; ++k) {
+            const double xw = X[k] / Wc[k], yw = Y[k] / Wc[k];
+            xmin = fmin(xmin, xw); xmax = fmax(xmax, xw);
+            ymin = fmin(ymin, yw); ymax = fmax(ymax, yw);
+        }
+        const double d = 1.0 / 1024.0;
+        double lo, hi;
+        lo = ceil(fmax(xmin - 0.5 - d, -1.0)); hi = floor(fmin(xmax - 0.5 + d, (double)W));
+        if (lo > (double)i_min) i_min = (int)lo;
+        if (hi < (double)i_max) i_max = (int)hi;
+        lo = ceil(fmax(ymin - 0.5 - d, -1.0)); hi = floor(fmin(ymax - 0.5 + d, (double)H));
+        if (lo > (double)j_min) j_min = (int)lo;
+        if (hi < (double)j_max) j_max = (int)hi;
+    }
+    if (i_min > i_max || j_min > j_max) return false;
+
+    uint32_t flags = FACE_VALID;
+    for (int k = 0; k < 3; ++k) {
+        const bool incl = (a[k] > 0.0) || (a[k] == 0.0 && b[k] > 0.0);
+        double zs = Z[k] * inv_det;
+        if (!incl) { a[k] = -a[k]; b[k] = -b[k]; c[k] = -c[k]; zs = -zs; flags |= (1u << k); }
+        rec.coef[3 * k + 0] = a[k]; rec.coef[3 * k + 1] = b[k]; rec.coef[3 * k + 2] = c[k];
+        rec.zs[k] = zs;
+    }
+    rec.flags = flags; rec.pad0 = 0; rec.pad1 = 0;
+    rec.inv_det = inv_det;
+    box.i_min = (int16_t)i_min; box.i_max = (int16_t)i_max;
+    box.r_min = (int16_t)(H - 1 - j_max); box.r_max = (int16_t)(H - 1 - j_min);
+    return true;
+}
+
+// Folded edge functions of one record at a sample.
+__device__ inline void edge_eval(const double* coef, double px, double py, double F[3])
+{
+    F[0] = fma(coef[0], px, fma(coef[1], py, coef[2]));
+    F[1] = fma(coef[3], px, fma(coef[4], py, coef[5]));
+    F[2] = fma(coef[6], px, fma(coef[7], py, coef[8]));
+}
+
+// Perspective-correct barycentrics and clip-space w of the fragment (csrc/shaders.cpp:52-57,74).
+__device__ inline void bary_eval(const double F[3], uint32_t flags, double inv_det, float b[3], float& clip_w)
+{
+    const double s0 = (flags & 1u) ? -inv_det : inv_det;
+    const double s1 = (flags & 2u) ? -inv_det : inv_det;
+    const double s2 = (flags & 4u) ? -inv_det : inv_det;
+    const float l0 = (float)(F[0] * s0), l1 = (float)(F[1] * s1), l2 = (float)(F[2] * s2);
+    const float s = (l0 + l1) + l2;
+    const float r = 1.0f / s;
+    b[0] = l0 * r; b[1] = l1 * r; b[2] = l2 * r;
+    clip_w = r;
+}
+
+}  // namespace dirt

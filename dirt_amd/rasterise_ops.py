@@ -1,0 +1,314 @@
+"""`dirt.rasterise_ops` for PyTorch-ROCm tensors on MI355X.
+
+Mirrors the reference's Python op API -- same function names, positional order, defaults, shapes
+and dtype coercions (dirt/rasterise_ops.py:13-108) and the same gradient wiring
+(dirt/rasterise_ops.py:111-129: gradients for [background, vertices, vertex_colors], None for
+faces) -- over torch tensors.  The TF custom ops `Rasterise` / `RasteriseGrad` are replaced by the
+C-ABI entry points of libdirt_hip.so (include/dirt_hip.h); tensors are handed over as raw device
+pointers together with the current HIP stream.  There is no CPU implementation, as in the
+reference (its kernels are DEVICE_GPU only, csrc/rasterise_egl.cpp:410): inputs must be on a GPU.
+
+Differences from the reference, by design:
+  * any `channels` >= 1 is one native call; the result equals the reference's channel-grouped
+    evaluation (dirt/rasterise_ops.py:86-108,132-177), which issues one op per group;
+  * the deferred wrappers rasterise visibility once per gradient call instead of once per group.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ['rasterise', 'rasterise_batch', 'rasterise_deferred', 'rasterise_batch_deferred']
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    """Grow-only scratch per (device, stream); the analogue of the reference's grow-only GL buffers
+    (csrc/rasterise_egl.cpp:325-333), but owned by the caller's allocator, not by the library."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _as_tensor(x, dtype, like=None):
+    """tf.convert_to_tensor(x, dtype=...) of dirt/rasterise_ops.py:44-47,68-71."""
+    if isinstance(x, torch.Tensor):
+        return x if x.dtype == dtype else x.to(dtype)
+    device = like.device if isinstance(like, torch.Tensor) else None
+    return torch.as_tensor(x, dtype=dtype, device=device)
+
+
+def _first_tensor(*xs):
+    for x in xs:
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            return x
+    for x in xs:
+        if isinstance(x, torch.Tensor):
+            return x
+    return None
+
+
+def _check_forward_shapes(background, vertices, vertex_colors, faces, height, width, channels):
+    # OP_REQUIRES conditions of csrc/rasterise_egl.cpp:301-316, same messages
+    if not (background.dim() == 4 and background.shape[1] == height and background.shape[2] == width
+            and background.shape[3] == channels):
+        raise ValueError('Rasterise expects background_tensor to be 4D, and bgcolor.shape == [None, height, width, channels]')
+    if not (vertices.dim() == 3 and vertices.shape[2] == 4):
+        raise ValueError('Rasterise expects vertices to be 3D, and vertices.shape[2] == 4')
+    if not (vertex_colors.dim() == 3 and vertex_colors.shape[1] == vertices.shape[1] and vertex_colors.shape[2] == channels):
+        raise ValueError('Rasterise expects vertex_colors to be 3D, and vertex_colors.shape == [None, vertices.shape[1], channels]')
+    if not (faces.dim() == 3 and faces.shape[2] == 3):
+        raise ValueError('Rasterise expects faces to be 3D, and faces.shape[2] == 3')
+    batch_size = vertices.shape[0]
+    if not (background.shape[0] == batch_size and vertex_colors.shape[0] == batch_size and faces.shape[0] == batch_size):
+        raise ValueError('Rasterise expects all arguments to have same leading (batch) dimension')
+
+
+def _check_backward_shapes(vertices, faces, pixels, grad_pixels):
+    # OP_REQUIRES conditions of csrc/rasterise_grad_egl.cpp:349-377
+    if not (vertices.dim() == 3 and vertices.shape[2] == 4):
+        raise ValueError('RasteriseGrad expects vertices to be 3D, and vertices.shape[2] == 4')
+    if not (faces.dim() == 3 and faces.shape[2] == 3):
+        raise ValueError('RasteriseGrad expects faces to be 3D, and faces.shape[2] == 3')
+    if pixels.dim() != 4:
+        raise ValueError('RasteriseGrad expects pixels to be 4D, and pixels.shape == [None, height, width, channels]')
+    if grad_pixels.dim() != 4 or grad_pixels.shape[1:] != pixels.shape[1:]:
+        raise ValueError('RasteriseGrad expects grad_pixels to be 4D, and grad_pixels.shape == [None, height, width, channels]')
+    batch_size = vertices.shape[0]
+    if not (faces.shape[0] == batch_size and pixels.shape[0] == batch_size and grad_pixels.shape[0] == batch_size):
+        raise ValueError('RasteriseGrad expects all arguments to have same leading (batch) dimension')
+
+
+def _require_gpu(*tensors):
+    dev = None
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                'dirt_amd ops run on an MI355X only (the reference registers its kernels for DEVICE_GPU only, '
+                'csrc/rasterise_egl.cpp:410); got a %s tensor. There is no CPU fallback.' % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError('all tensors must be on the same device (%s vs %s)' % (dev, t.device))
+    return dev
+
+
+def _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels):
+    """`_rasterise_module.rasterise` (dirt/rasterise_ops.py:81-85): the raw forward op, no autograd."""
+    lib = _lib.load()
+    _check_forward_shapes(background, vertices, vertex_colors, faces, height, width, channels)
+    dev = _require_gpu(background, vertices, vertex_colors, faces)
+    background, vertices, vertex_colors, faces = (t.contiguous() for t in (background, vertices, vertex_colors, faces))
+    B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[1]
+    pixels = torch.empty_like(background)
+    with torch.cuda.device(dev):
+        nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, channels)
+        if nbytes == 0:
+            raise ValueError(_lib.last_error())
+        ws = _workspace(dev, nbytes)
+        _lib.check(lib.dirt_rasterise_forward(
+            background.data_ptr(), vertices.data_ptr(), vertex_colors.data_ptr(), faces.data_ptr(), pixels.data_ptr(),
+            B, V, F, height, width, channels, ws.data_ptr(), ws.numel(), 0, torch.cuda.current_stream(dev).cuda_stream))
+    return pixels
+
+
+def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, channels, flags=0, want_debug=False):
+    """`_rasterise_module.rasterise_grad` (dirt/rasterise_ops.py:113-118): returns
+    (grad_background, grad_vertices, grad_vertex_colors, debug_thingy or None)."""
+    lib = _lib.load()
+    _check_backward_shapes(vertices, faces, pixels, grad_pixels)
+    if tuple(pixels.shape[1:]) != (height, width, channels):
+        raise ValueError('RasteriseGrad expects pixels to be 4D, and pixels.shape == [None, height, width, channels]')
+    dev = _require_gpu(vertices, faces, pixels, grad_pixels)
+    vertices, faces, pixels, grad_pixels = (t.contiguous() for t in (vertices, faces, pixels, grad_pixels))
+    B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[1]
+    grad_background = torch.empty_like(pixels)
+    grad_vertices = torch.empty_like(vertices)
+    grad_vertex_colors = torch.empty((B, V, channels), dtype=torch.float32, device=dev)
+    debug = torch.empty((B, height, width, 3), dtype=torch.float32, device=dev) if want_debug else None
+    with torch.cuda.device(dev):
+        nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, channels)
+        if nbytes == 0:
+            raise ValueError(_lib.last_error())
+        ws = _workspace(dev, nbytes)
+        _lib.check(lib.dirt_rasterise_backward(
+            vertices.data_ptr(), faces.data_ptr(), pixels.data_ptr(), grad_pixels.data_ptr(),
+            grad_background.data_ptr(), grad_vertices.data_ptr(), grad_vertex_colors.data_ptr(),
+            debug.data_ptr() if want_debug else None,
+            B, V, F, height, width, channels, ws.data_ptr(), ws.numel(), flags,
+            torch.cuda.current_stream(dev).cuda_stream))
+    return grad_background, grad_vertices, grad_vertex_colors, debug
+
+
+def _op_visibility(vertices, faces, height, width):
+    """Front-most face per pixel, [B,H,W] int32 (-1 = background)."""
+    lib = _lib.load()
+    dev = _require_gpu(vertices, faces)
+    vertices, faces = vertices.contiguous(), faces.contiguous()
+    B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[1]
+    face_id = torch.empty((B, height, width), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, 1)
+        ws = _workspace(dev, nbytes)
+        _lib.check(lib.dirt_rasterise_visibility(
+            vertices.data_ptr(), faces.data_ptr(), face_id.data_ptr(), B, V, F, height, width,
+            ws.data_ptr(), ws.numel(), 0, torch.cuda.current_stream(dev).cuda_stream))
+    return face_id
+
+
+class _Rasterise(torch.autograd.Function):
+    """The `Rasterise` op with its registered gradient (dirt/rasterise_ops.py:111-129)."""
+
+    @staticmethod
+    def forward(ctx, background, vertices, vertex_colors, faces, height, width, channels):
+        pixels = _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels)
+        ctx.save_for_backward(vertices, faces, pixels)  # op.inputs[1], op.inputs[3], op.outputs[0]
+        ctx.hwc = (height, width, channels)
+        return pixels
+
+    @staticmethod
+    def backward(ctx, grad_pixels):
+        vertices, faces, pixels = ctx.saved_tensors
+        height, width, channels = ctx.hwc
+        grad_background, grad_vertices, grad_vertex_colors, _ = _op_rasterise_grad(
+            vertices, faces, pixels, grad_pixels.to(torch.float32), height, width, channels)
+        return grad_background, grad_vertices, grad_vertex_colors, None, None, None, None  # None wrt faces
+
+
+def rasterise(background, vertices, vertex_colors, faces, height=None, width=None, channels=None, name=None):
+    """Rasterises the given `vertices` and `faces` over `background` (dirt/rasterise_ops.py:13-48).
+
+    Args:
+        background: float32 tensor [height, width, channels], the image to render over
+        vertices: float32 tensor [vertex count, 4], vertex locations in OpenGL clip space
+        vertex_colors: float32 tensor [vertex count, channels]; interpolated perspective-correctly
+        faces: int32 tensor [face count, 3] of indices into `vertices`
+        height, width, channels: python ints; inferred from `background` when None
+        name: ignored (kept for signature compatibility)
+
+    Returns: float32 tensor [height, width, channels], top row first.
+    """
+    like = _first_tensor(background, vertices, vertex_colors, faces)
+    background = _as_tensor(background, torch.float32, like)
+    vertices = _as_tensor(vertices, torch.float32, like)
+    vertex_colors = _as_tensor(vertex_colors, torch.float32, like)
+    faces = _as_tensor(faces, torch.int32, like)
+    return rasterise_batch(background[None], vertices[None], vertex_colors[None], faces[None], height, width, channels, name)[0]
+
+
+def rasterise_batch(background, vertices, vertex_colors, faces, height=None, width=None, channels=None, name=None):
+    """Rasterises a batch of meshes with the same numbers of vertices and faces
+    (dirt/rasterise_ops.py:51-108); every argument of `rasterise` gains a leading batch dimension."""
+    like = _first_tensor(background, vertices, vertex_colors, faces)
+    background = _as_tensor(background, torch.float32, like)
+    vertices = _as_tensor(vertices, torch.float32, like)
+    vertex_colors = _as_tensor(vertex_colors, torch.float32, like)
+    faces = _as_tensor(faces, torch.int32, like)
+    if background.dim() != 4:
+        raise ValueError('Rasterise expects background_tensor to be 4D, and bgcolor.shape == [None, height, width, channels]')
+    if height is None:
+        height = int(background.shape[1])
+    if width is None:
+        width = int(background.shape[2])
+    if channels is None:
+        channels = int(background.shape[3])
+    assert channels > 0  # dirt/rasterise_ops.py:87
+    return _Rasterise.apply(background, vertices, vertex_colors, faces, int(height), int(width), int(channels))
+
+
+def _rasterise_grad_multichannel(vertices, faces, pixels, d_loss_by_pixels, single_or_batch):
+    """dirt/rasterise_ops.py:132-177; one native call evaluates every channel group."""
+    assert single_or_batch in ['single', 'batch']
+    if single_or_batch == 'single':
+        vertices, faces, pixels, d_loss_by_pixels = vertices[None], faces[None], pixels[None], d_loss_by_pixels[None]
+    assert pixels.dim() == 4
+    height, width, channels = (int(s) for s in pixels.shape[1:])
+    gb, gv, gvc, _ = _op_rasterise_grad(vertices, faces, pixels, d_loss_by_pixels, height, width, channels)
+    if single_or_batch == 'single':
+        return {'grad_vertices': gv[0], 'grad_vertex_colors': gvc[0], 'grad_background': gb[0]}
+    return {'grad_vertices': gv, 'grad_vertex_colors': gvc, 'grad_background': gb}
+
+
+class _RasteriseDeferred(torch.autograd.Function):
+    """`_rasterise_deferred_internal._impl` (dirt/rasterise_ops.py:189-248) as a custom autograd node."""
+
+    @staticmethod
+    def forward(ctx, shader_fn, single_or_batch, n_extra, vertices, faces, attributes, background, *rest):
+        shader_additional_inputs = rest[:n_extra]
+        shader_params = rest[n_extra:]  # parameters closed over by shader_fn (TF's `variables`)
+        fwd = rasterise if single_or_batch == 'single' else rasterise_batch
+        with torch.no_grad():
+            gbuffer = fwd(background, vertices, attributes, faces)
+        with torch.enable_grad():
+            gbuffer_in = gbuffer.detach().requires_grad_(True)
+            extra_in = [t.detach().requires_grad_(t.is_floating_point()) if isinstance(t, torch.Tensor) else t
+                        for t in shader_additional_inputs]
+            pixels = shader_fn(gbuffer_in, *extra_in)
+        ctx.single_or_batch = single_or_batch
+        ctx.n_extra = n_extra
+        ctx.n_params = len(shader_params)
+        ctx.graph = (gbuffer_in, extra_in, pixels, shader_params)
+        ctx.save_for_backward(vertices, faces)
+        return pixels.detach()
+
+    @staticmethod
+    def backward(ctx, d_loss_by_pixels):
+        vertices, faces = ctx.saved_tensors
+        gbuffer_in, extra_in, pixels, shader_params = ctx.graph
+        sob = ctx.single_or_batch
+        # vertex gradients from filtering the SHADED image (dirt/rasterise_ops.py:204-210)
+        d_loss_by_vertices = _rasterise_grad_multichannel(
+            vertices, faces, pixels.detach(), d_loss_by_pixels.contiguous(), sob)['grad_vertices']
+        # backprop through shader_fn to the G-buffer (dirt/rasterise_ops.py:212-229)
+        diff_extra = [t for t in extra_in if isinstance(t, torch.Tensor) and t.requires_grad]
+        diff_params = [t for t in shader_params if isinstance(t, torch.Tensor) and t.requires_grad]
+        grads = torch.autograd.grad(pixels, [gbuffer_in] + diff_extra + diff_params, d_loss_by_pixels, allow_unused=True)
+        d_loss_by_gbuffer = grads[0]
+        if d_loss_by_gbuffer is None:
+            d_loss_by_gbuffer = torch.zeros_like(gbuffer_in)
+        extra_grads = iter(grads[1:1 + len(diff_extra)])
+        param_grads = iter(grads[1 + len(diff_extra):])
+        # attribute / background gradients from the G-buffer (dirt/rasterise_ops.py:231-237)
+        d_attr = _rasterise_grad_multichannel(vertices, faces, gbuffer_in.detach(), d_loss_by_gbuffer.contiguous(), sob)
+        out = [None, None, None, d_loss_by_vertices, None, d_attr['grad_vertex_colors'], d_attr['grad_background']]
+        for t in extra_in:
+            out.append(next(extra_grads) if isinstance(t, torch.Tensor) and t.requires_grad else None)
+        for t in shader_params:
+            out.append(next(param_grads) if isinstance(t, torch.Tensor) and t.requires_grad else None)
+        return tuple(out)
+
+
+def _rasterise_deferred_internal(background, vertices, attributes, faces, shader_fn, shader_additional_inputs,
+                                 single_or_batch, name, shader_parameters=()):
+    like = _first_tensor(background, vertices, attributes, faces)
+    background = _as_tensor(background, torch.float32, like)
+    vertices = _as_tensor(vertices, torch.float32, like)
+    attributes = _as_tensor(attributes, torch.float32, like)
+    faces = _as_tensor(faces, torch.int32, like)
+    extra = [t if isinstance(t, torch.Tensor) else torch.as_tensor(t, device=background.device)
+             for t in shader_additional_inputs]
+    params = list(shader_parameters)
+    return _RasteriseDeferred.apply(shader_fn, single_or_batch, len(extra), vertices, faces, attributes, background,
+                                    *extra, *params)
+
+
+def rasterise_deferred(background_attributes, vertices, vertex_attributes, faces, shader_fn,
+                       shader_additional_inputs=[], name=None, shader_parameters=()):
+    """Rasterises a G-buffer of `vertex_attributes` and shades it with `shader_fn`
+    (dirt/rasterise_ops.py:260-310).  Equivalent to
+    `shader_fn(rasterise(background_attributes, vertices, vertex_attributes, faces), *shader_additional_inputs)`
+    but the vertex gradient is obtained by filtering the shaded image.  Tensors that `shader_fn`
+    depends on must be passed through `shader_additional_inputs`; `torch.nn.Parameter`s it closes over
+    may be listed in `shader_parameters` (the counterpart of TF's `variables`)."""
+    return _rasterise_deferred_internal(background_attributes, vertices, vertex_attributes, faces, shader_fn,
+                                        shader_additional_inputs, 'single', name, shader_parameters)
+
+
+def rasterise_batch_deferred(background_attributes, vertices, vertex_attributes, faces, shader_fn,
+                             shader_additional_inputs=[], name=None, shader_parameters=()):
+    """Batched `rasterise_deferred` (dirt/rasterise_ops.py:313-332)."""
+    return _rasterise_deferred_internal(background_attributes, vertices, vertex_attributes, faces, shader_fn,
+                                        shader_additional_inputs, 'batch', name, shader_parameters)

@@ -1,0 +1,138 @@
+"""Synthetic scene generators for tests, smoke and bench (numpy only).
+
+K1 = the quad of the reference's tests/square_test.py:20-36; K2 = the cube of samples/simple.py:15-66;
+K3/K4/K5 = `rand_mesh` scenes.  Everything is deterministic in its seed.
+"""
+import math
+import numpy as np
+
+
+def square_scene():
+    """tests/square_test.py:6-8,20-36 verbatim: 128x128x1, 2-triangle 16x16 square centred at (32, 64)."""
+    w = h = 128
+    cx, cy, size = 32, 64, 16
+    v = np.array([[0, 0], [0, 1], [1, 1], [1, 0]], np.float32) * size - size / 2.
+    v = v + np.array([cx, cy], np.float32)
+    v = v * 2. / np.array([w, h], np.float32) - 1.
+    vertices = np.concatenate([v, np.zeros([4, 1], np.float32), np.ones([4, 1], np.float32)], axis=1).astype(np.float32)
+    faces = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    return dict(background=np.zeros([h, w, 1], np.float32), vertices=vertices,
+                vertex_colors=np.ones([4, 1], np.float32), faces=faces, height=h, width=w, channels=1)
+
+
+def square_expected():
+    """tests/square_test.py:11-17: the analytic mask the reference compares against."""
+    w = h = 128
+    xs, ys = np.meshgrid(np.arange(w), np.arange(h))
+    xs = xs.astype(np.float32) + 0.5
+    ys = ys.astype(np.float32) + 0.5
+    return ((np.abs(xs - 32) <= 8) & (np.abs(ys - 64) <= 8)).astype(np.float32)
+
+
+def rand_mesh(face_count, seed, r_lo, r_hi, shared=False):
+    """SURVEY.md 8d `rand_mesh`: random perspective triangles, all w > 0.
+
+    Returns (vertices [V,4] clip space float32, faces [F,3] int32).  `shared=True` gives the
+    shared-vertex variant (a jittered grid, V ~ F/2) that stresses atomics."""
+    rng = np.random.default_rng(seed)
+    F = int(face_count)
+    if not shared:
+        c = rng.uniform(-1, 1, [F, 1, 2])
+        r = rng.uniform(r_lo, r_hi, [F, 1, 1])
+        th0 = rng.uniform(0, 2 * math.pi, [F, 1])
+        th = th0 + 2 * math.pi * np.arange(3)[None, :] / 3 + rng.uniform(-0.5, 0.5, [F, 3])
+        ndc_xy = c + r * np.stack([np.cos(th), np.sin(th)], axis=-1)
+        ndc_z = rng.uniform(-0.9, 0.9, [F, 3, 1])
+        d = rng.uniform(1, 4, [F, 1, 1])
+        w = d * (1 + rng.uniform(-0.1, 0.1, [F, 3, 1]))
+        verts = np.concatenate([ndc_xy * w, ndc_z * w, w], axis=-1).reshape(F * 3, 4).astype(np.float32)
+        faces = np.arange(F * 3, dtype=np.int32).reshape(F, 3)
+        return verts, faces
+    n = max(2, int(math.ceil(math.sqrt(F / 2.0))) + 1)
+    gx, gy = np.meshgrid(np.linspace(-1.05, 1.05, n), np.linspace(-1.05, 1.05, n))
+    jit = rng.uniform(-0.3, 0.3, [n, n, 2]) * (2.1 / (n - 1))
+    ndc_xy = np.stack([gx, gy], -1) + jit
+    ndc_z = rng.uniform(-0.9, 0.9, [n, n, 1])
+    w = rng.uniform(1, 4, [n, n, 1])
+    verts = np.concatenate([ndc_xy * w, ndc_z * w, w], axis=-1).reshape(n * n, 4).astype(np.float32)
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c_, d_ = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel(), idx[1:, :-1].ravel()
+    faces = np.concatenate([np.stack([a, b, c_], 1), np.stack([a, c_, d_], 1)], 0)
+    faces = faces[rng.permutation(len(faces))][:F].astype(np.int32)
+    return verts, faces
+
+
+def rand_scene(face_count, height, width, channels, seed, r_lo=0.005, r_hi=0.04, shared=False):
+    """A full single scene: mesh + U(0,1) colours/background + N(0,1) grad_pixels."""
+    verts, faces = rand_mesh(face_count, seed, r_lo, r_hi, shared)
+    rng = np.random.default_rng(seed + 100003)
+    V = verts.shape[0]
+    return dict(
+        background=rng.uniform(0, 1, [height, width, channels]).astype(np.float32),
+        vertices=verts, faces=faces,
+        vertex_colors=rng.uniform(0, 1, [V, channels]).astype(np.float32),
+        grad_pixels=rng.standard_normal([height, width, channels]).astype(np.float32),
+        height=height, width=width, channels=channels)
+
+
+def batch_scene(face_count, height, width, channels, seeds, **kw):
+    """Stack `rand_scene`s along a leading batch dimension (K4)."""
+    ss = [rand_scene(face_count, height, width, channels, s, **kw) for s in seeds]
+    out = {k: np.stack([s[k] for s in ss]) for k in ('background', 'vertices', 'faces', 'vertex_colors', 'grad_pixels')}
+    out.update(height=height, width=width, channels=channels)
+    return out
+
+
+CONFIGS = {
+    # name: (F, H, W, C, seed, r_lo, r_hi)   -- BASELINE.md section 3
+    'K3': (10000, 1024, 1024, 4, 0, 0.005, 0.04),
+    'K3-256': (10000, 256, 256, 4, 0, 0.005, 0.04),
+    'K3-2048': (10000, 2048, 2048, 4, 0, 0.005, 0.04),
+    'K5': (50000, 2048, 2048, 16, 1, 0.002, 0.018),
+}
+
+
+def config_scene(name):
+    F, H, W, C, seed, r_lo, r_hi = CONFIGS[name]
+    return rand_scene(F, H, W, C, seed, r_lo, r_hi)
+
+
+def _rodrigues(v):
+    v = np.asarray(v, np.float64) + 1e-12
+    n = np.linalg.norm(v)
+    k = v / n
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = math.cos(n) * np.eye(3) + (1 - math.cos(n)) * np.outer(k, k) + math.sin(n) * K
+    M = np.eye(4)
+    M[:3, :3] = R
+    return M
+
+
+def cube_scene(height=256, width=256):
+    """K2: the Gouraud cube of samples/simple.py:15-66 (split vertices, lit colours), numpy restatement."""
+    verts = np.array([[x, y, z] for z in [-1, 1] for y in [-1, 1] for x in [-1, 1]], np.float64)
+    quads = [[0, 1, 3, 2], [4, 5, 7, 6], [1, 5, 4, 0], [2, 6, 7, 3], [4, 6, 2, 0], [3, 7, 5, 1]]
+    tris = np.array(sum([[[a, b, c], [c, d, a]] for a, b, c, d in quads], []), np.int32)
+    v = verts[tris.reshape(-1)]                                   # split_vertices_by_face
+    faces = np.arange(len(v), dtype=np.int32).reshape(-1, 3)
+    v = np.concatenate([v, np.ones([len(v), 1])], 1)
+    world = v @ _rodrigues([0., 0.5, 0.])
+    tri = world[:, :3].reshape(-1, 3, 3)
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    n /= (np.linalg.norm(n, axis=-1, keepdims=True) + 1e-12)
+    normals = np.repeat(n, 3, axis=0)
+    T = np.eye(4)
+    T[3, :3] = [0., -1.5, -3.5]
+    view = T @ _rodrigues([-0.3, 0., 0.])
+    cam = world @ view
+    near, far, right = 0.1, 20., 0.1
+    top = right * float(height) / width
+    Pm = np.array([[near / right, 0, 0, 0], [0, near / top, 0, 0],
+                   [0, 0, -(far + near) / (far - near), -2. * far * near / (far - near)], [0, 0, -1., 0]]).T
+    clip = cam @ Pm
+    light = np.array([1., 0., 0.])
+    light /= np.linalg.norm(light)
+    diffuse = np.abs(normals @ -light)[:, None] * np.ones([1, 3])
+    colors = diffuse * 0.8 + 0.2
+    return dict(background=np.zeros([height, width, 3], np.float32), vertices=clip.astype(np.float32),
+                vertex_colors=colors.astype(np.float32), faces=faces, height=height, width=width, channels=3)

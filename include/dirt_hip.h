@@ -1,0 +1,109 @@
+/*
+ * dirt_hip.h -- C ABI of libdirt_hip.so, the MI355X (gfx950) replacement for the two TensorFlow
+ * custom ops of pmh47/dirt.  Plain C, raw device pointers and sizes; no torch / TF / HIP types.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository root).  The reference binds its ops through the TF op registry
+ * (dirt/rasterise_ops.py:5-10: tf.load_op_library('librasterise.so')); a maintainer binds this
+ * library with ctypes -- see INTEGRATION.md for the stub.
+ *
+ * Conventions shared by every call
+ *   - all tensors are dense, row-major, float32 except `faces` (int32); device pointers;
+ *   - background / pixels / grad_* images are [B,H,W,C], top row first (README.md:183);
+ *     vertices [B,V,4] are OpenGL clip-space (x,y,z,w); vertex_colors [B,V,C]; faces [B,F,3];
+ *   - `workspace` is caller-owned device scratch of at least dirt_workspace_bytes(...) bytes,
+ *     16-byte aligned; the library keeps no device state between calls (re-entrant);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); work is enqueued
+ *     asynchronously on it and the call returns without synchronising;
+ *   - the current HIP device must be the one that owns the pointers;
+ *   - return value 0 = success, <0 = DIRT_E_* below; dirt_last_error() describes the last
+ *     failure on the calling thread.  The library never aborts the process.
+ */
+#ifndef DIRT_HIP_H
+#define DIRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIRT_ABI_VERSION 1
+
+/* error codes */
+#define DIRT_OK 0
+#define DIRT_E_INVALID_ARGUMENT (-1) /* bad sizes / null pointers: the OP_REQUIRES checks of
+                                        csrc/rasterise_egl.cpp:301-316, csrc/rasterise_grad_egl.cpp:349-377
+                                        and the CHECKs of csrc/hwc.h:27-28 */
+#define DIRT_E_TOO_MANY_VERTICES (-2) /* V > 2^24: csrc/rasterise_grad_egl.cpp:399-405 */
+#define DIRT_E_WORKSPACE (-3)         /* workspace NULL / too small / misaligned */
+#define DIRT_E_HIP (-4)               /* a HIP runtime call failed (the reference LOG(FATAL)s) */
+
+/* flags (bitwise or) */
+#define DIRT_FLAG_Q1_INTENDED 1u /* backward: for 1-channel groups take the Scharr L1 over the one
+                                    real channel instead of reproducing the reference's out-of-range
+                                    channel reads (csrc/rasterise_grad_egl.cu:119-123,185; SURVEY.md
+                                    App. A.3 quirk Q1).  Default (0) reproduces the reference. */
+
+/* Limits of this implementation (the reference's limit is the GL max texture size of its atlas). */
+#define DIRT_MAX_DIM 16384
+
+/* Returns DIRT_ABI_VERSION of the loaded library. */
+int dirt_abi_version(void);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char *dirt_last_error(void);
+
+/*
+ * Scratch bytes needed by dirt_rasterise_forward / dirt_rasterise_backward for these sizes
+ * (replaces the grow-only GL buffers / framebuffer atlas the reference caches per thread,
+ * csrc/rasterise_egl.cpp:325-346, csrc/rasterise_grad_egl.cpp:407-425).  Returns 0 on invalid sizes.
+ */
+size_t dirt_workspace_bytes(int B, int V, int F, int H, int W, int C);
+
+/*
+ * Forward.  Replaces the `Rasterise` op: REGISTER_OP csrc/rasterise_egl.cpp:32-51 and
+ * RasteriseOpGpu::Compute csrc/rasterise_egl.cpp:276-407, as called from
+ * dirt/rasterise_ops.py:81-85,98-105.  Unlike the reference op, C may be any value >= 1: the
+ * result equals the reference's channel-grouped evaluation (dirt/rasterise_ops.py:86-108).
+ *   in : background [B,H,W,C], vertices [B,V,4], vertex_colors [B,V,C], faces [B,F,3]
+ *   out: pixels [B,H,W,C]
+ * B, V or F may be 0 (pixels = background when there is nothing to draw).
+ */
+int dirt_rasterise_forward(const float *background, const float *vertices, const float *vertex_colors,
+                           const int32_t *faces, float *pixels, int B, int V, int F, int H, int W, int C,
+                           void *workspace, size_t workspace_bytes, unsigned flags, void *stream);
+
+/*
+ * Backward.  Replaces the `RasteriseGrad` op: REGISTER_OP csrc/rasterise_grad_egl.cpp:33-53,
+ * Compute csrc/rasterise_grad_egl.cpp:324-485 and launch_grad_assembly / assemble_grads
+ * csrc/rasterise_grad_egl.cu:93-278, as called from dirt/rasterise_ops.py:113-118,154-160; for C
+ * not in {1,3} it reproduces _rasterise_grad_multichannel (dirt/rasterise_ops.py:132-177):
+ * channel groups of 3 then 1s, grad_vertices summed over groups, the others concatenated.
+ *   in : vertices [B,V,4], faces [B,F,3], pixels [B,H,W,C] (the forward output), grad_pixels [B,H,W,C]
+ *   out: grad_background [B,H,W,C], grad_vertices [B,V,4], grad_vertex_colors [B,V,C],
+ *        debug_thingy [B,H,W,3] or NULL (the reference's 4th, diagnostic output, of the first
+ *        channel group; csrc/rasterise_grad_egl.cu:150-151,172)
+ * All outputs are fully written (zero where the reference's memsets leave zero,
+ * csrc/rasterise_grad_egl.cu:244-250).  Float atomics make grad_vertices / grad_vertex_colors
+ * order-dependent in the last bits, as in the reference.
+ */
+int dirt_rasterise_backward(const float *vertices, const int32_t *faces, const float *pixels,
+                            const float *grad_pixels, float *grad_background, float *grad_vertices,
+                            float *grad_vertex_colors, float *debug_thingy, int B, int V, int F, int H, int W,
+                            int C, void *workspace, size_t workspace_bytes, unsigned flags, void *stream);
+
+/*
+ * Visibility only (no reference counterpart as an op; it is the render pass of
+ * csrc/rasterise_grad_egl.cpp:432-456 exposed for tests and for the deferred-shading row):
+ *   out: face_id [B,H,W] int32, index of the front-most face or -1.
+ */
+int dirt_rasterise_visibility(const float *vertices, const int32_t *faces, int32_t *face_id, int B, int V,
+                              int F, int H, int W, void *workspace, size_t workspace_bytes, unsigned flags,
+                              void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIRT_HIP_H */
