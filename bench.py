@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- forward+backward Mpixels/s of the dirt rasterise hot path on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
+driver launches it under torch.distributed.run, one rank per GPU.  A "step" is one
+dirt_rasterise_forward + one dirt_rasterise_backward over one batch of synthetic scenes resident in
+HBM.  Rank 0 prints ONE JSON line.
+
+Workload: BASELINE.json's metric config K3 -- a 10 000-triangle random mesh rendered at
+1024x1024x4 channels (SURVEY.md 8d `rand_mesh`, seed 0 + scene index), `--scenes-per-gpu` scenes per
+rank (default 1 = K3 itself; 8 per rank on 8 GPUs is K4).  Scenes are independent, so ranks share
+nothing on the data path (weak scaling, no collective inside the timed region; DESIGN.md "Multi-GPU").
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (by summed HIP-event time over the timed steps) against the HBM
+                  roofline: achieved = that kernel's algorithmic bytes per launch / its mean duration.
+  cpu_baseline -- the CPU oracle ("port" of the reference's algorithm; the reference op itself is
+                  GPU-only) timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(P, V, F, C):
+    """compulsory tensor traffic of one scene, forward + backward."""
+    return 20 * P * C + 48 * V + 8 * V * C + 24 * F
+
+
+def kernel_algorithmic_bytes(P, V, F, C):
+    """Share of the 8d figure each kernel is responsible for (DESIGN.md "Kernels"), per scene.
+    Set-up reads faces + vertices (counted once per pass that runs it); raster<shade> reads the
+    background and vertex colours and writes pixels; raster<visibility> has no algorithmic traffic
+    of its own (its output is an intermediate); grad reads pixels, grad_pixels, vertices and writes
+    the three gradients."""
+    return {
+        'setup_kernel': 12 * F + 16 * V,
+        'raster_kernel<shade>': 8 * P * C + 4 * V * C,
+        'raster_kernel<visibility>': 0,
+        'grad_kernel': 12 * P * C + 16 * V + 16 * V + 4 * V * C,
+        'memset': 0,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--scenes-per-gpu', type=int, default=1)
+    ap.add_argument('--config', default='K3', help='K3 | K3-256 | K3-2048 | K5')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)
+
+    from dirt_amd import scenes, _lib, rasterise_ops as ops
+    _lib.load()
+
+    F, H, W, C, seed0, r_lo, r_hi = scenes.CONFIGS[args.config]
+    spg = args.scenes_per_gpu
+    seeds = [seed0 + rank * spg + i for i in range(spg)]
+    batch = scenes.batch_scene(F, H, W, C, seeds, r_lo=r_lo, r_hi=r_hi)
+    V = batch['vertices'].shape[1]
+    P = H * W
+
+    def t(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    bg, v, vc, f, g = (t(batch[k]) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels'))
+
+    def step(flags=0):
+        px = ops._op_rasterise(bg, v, vc, f, H, W, C, flags=flags)
+        return ops._op_rasterise_grad(v, f, px, g, H, W, C, flags=flags)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    total_pixels = world * spg * P
+    value = total_pixels / (elapsed / args.steps) / 1e6
+
+    # ---- per-kernel HIP-event timing over a second, identical timed region (rank 0 only) ----
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        _lib.profile_reset()
+        torch.cuda.synchronize()
+        for _ in range(args.steps):
+            step(_lib.FLAG_PROFILE)
+        torch.cuda.synchronize()
+        prof = _lib.profile_read()
+        kbytes = kernel_algorithmic_bytes(P, V, F, C)
+        for name, (ms, n) in prof.items():
+            if n:
+                kernels[name] = {'launches_per_step': n / args.steps, 'avg_us': ms / n * 1e3,
+                                 'us_per_step': ms / args.steps * 1e3}
+        dom = max(kernels, key=lambda k: kernels[k]['us_per_step'])
+        avg_s = kernels[dom]['avg_us'] * 1e-6
+        per_launch = kbytes[dom] * spg
+        achieved = per_launch / avg_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')  # written by tools/pmc_summary.py from rocprofv3 --pmc passes
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.config, {}).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                    'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+                    'algorithmic_bytes_per_launch': per_launch, 'avg_launch_us': kernels[dom]['avg_us']}
+
+    # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N == 1) ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        oracle.build()
+        cores = os.cpu_count() or 1
+        oracle.set_num_threads(cores)
+        one = {k: batch[k][:1] for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
+        oracle.forward(one['background'], one['vertices'], one['vertex_colors'], one['faces'])  # warm
+        n_it, t_cpu = 0, 0.0
+        while t_cpu < args.cpu_seconds and n_it < 20:
+            c0 = time.perf_counter()
+            px = oracle.forward(one['background'], one['vertices'], one['vertex_colors'], one['faces'])
+            oracle.backward(one['vertices'], one['faces'], px, one['grad_pixels'])
+            t_cpu += time.perf_counter() - c0
+            n_it += 1
+        cpu_baseline = {'value': n_it * P / t_cpu / 1e6, 'unit': 'Mpixels/s', 'cores': oracle.num_threads(),
+                        'kind': 'port',
+                        'sample': '%d x forward+backward of one %s scene (%dx%dx%d, %d triangles), oracle/dirt_oracle.c with OpenMP'
+                                  % (n_it, args.config, H, W, C, F)}
+
+    if rank == 0:
+        step_bytes = algorithmic_bytes(P, V, F, C) * spg
+        out = {
+            'metric': 'forward+backward Mpixels/s at 1024x1024x4ch, 10k-tri mesh' if args.config == 'K3'
+                      else 'forward+backward Mpixels/s (%s)' % args.config,
+            'value': value, 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (f64 edge functions)', 'data': 'synthetic',
+            'config': {'workload': '%s: rand_mesh F=%d at %dx%dx%d, %d scene(s) per GPU, forward+backward'
+                                   % (args.config, F, H, W, C, spg),
+                       'scenes_per_gpu': spg, 'parallelism': 'batch-sharded x%d, no collective' % world},
+            'roofline': roofline,
+            'roofline_step': {'algorithmic_bytes': step_bytes, 'achieved': step_bytes / (ms_per_step * 1e-3) / 1e9,
+                              'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                              'frac': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            'kernels': kernels,
+            'cpu_baseline': cpu_baseline,
+        }
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libdirt_hip.so')
 ABI_VERSION = 1
 
 FLAG_Q1_INTENDED = 1
+FLAG_PROFILE = 0x100
 
 E_INVALID_ARGUMENT = -1
 E_TOO_MANY_VERTICES = -2
@@ -23,7 +24,8 @@ _lib = None
 
 # every symbol include/dirt_hip.h declares (tests/test_boundary.py checks header <-> library)
 SYMBOLS = ('dirt_abi_version', 'dirt_last_error', 'dirt_workspace_bytes', 'dirt_rasterise_forward',
-           'dirt_rasterise_backward', 'dirt_rasterise_visibility')
+           'dirt_rasterise_backward', 'dirt_rasterise_visibility', 'dirt_profile_count', 'dirt_profile_name',
+           'dirt_profile_read', 'dirt_profile_reset')
 
 
 class DirtLibraryError(RuntimeError):
@@ -55,6 +57,12 @@ def load():
     lib.dirt_rasterise_backward.restype = i
     lib.dirt_rasterise_visibility.argtypes = [fp, ip, ip, i, i, i, i, i, vp, sz, u, vp]
     lib.dirt_rasterise_visibility.restype = i
+    lib.dirt_profile_count.restype = i
+    lib.dirt_profile_name.argtypes = [i]
+    lib.dirt_profile_name.restype = ctypes.c_char_p
+    lib.dirt_profile_read.argtypes = [i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
+    lib.dirt_profile_read.restype = i
+    lib.dirt_profile_reset.restype = i
     if lib.dirt_abi_version() != ABI_VERSION:
         raise DirtLibraryError('libdirt_hip.so ABI %d != expected %d' % (lib.dirt_abi_version(), ABI_VERSION))
     _lib = lib
@@ -75,3 +83,18 @@ def check(rc):
     if rc in (E_INVALID_ARGUMENT, E_TOO_MANY_VERTICES, E_WORKSPACE):
         raise ValueError(msg)
     raise RuntimeError(msg)
+
+
+def profile_reset():
+    check(load().dirt_profile_reset())
+
+
+def profile_read():
+    """{kernel name: (total_ms, launches)} for calls made with FLAG_PROFILE on this thread."""
+    lib = load()
+    out = {}
+    for slot in range(lib.dirt_profile_count()):
+        ms, n = ctypes.c_double(0), ctypes.c_longlong(0)
+        check(lib.dirt_profile_read(slot, ctypes.byref(ms), ctypes.byref(n)))
+        out[lib.dirt_profile_name(slot).decode()] = (ms.value, n.value)
+    return out

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 #include "../../include/dirt_hip.h"
 #include "dirt_launch.h"
 
@@ -19,6 +20,61 @@ int fail(int code, const char* fmt, ...)
     vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
     return code;
+}
+
+// ---- optional per-kernel HIP-event timing (DIRT_FLAG_PROFILE) ----------------------------------
+enum Slot { SLOT_SETUP = 0, SLOT_RASTER_FWD, SLOT_RASTER_VIS, SLOT_GRAD, SLOT_MEMSET, SLOT_COUNT };
+const char* const kSlotNames[SLOT_COUNT] = {"setup_kernel", "raster_kernel<shade>", "raster_kernel<visibility>",
+                                            "grad_kernel", "memset"};
+struct Pending {
+    hipEvent_t a, b;
+    int slot;
+};
+struct Profile {
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[SLOT_COUNT] = {0};
+    long long launches[SLOT_COUNT] = {0};
+};
+thread_local Profile g_prof;
+
+struct Scope {  // records an event pair around the launches issued during its lifetime
+    bool on;
+    hipStream_t stream;
+    Pending p;
+    static hipEvent_t get()
+    {
+        if (!g_prof.pool.empty()) { hipEvent_t e = g_prof.pool.back(); g_prof.pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    Scope(bool enabled, int slot, hipStream_t s) : on(enabled && g_prof.pending.size() < 65536), stream(s)
+    {
+        if (!on) return;
+        p.slot = slot; p.a = get(); p.b = get();
+        (void)hipEventRecord(p.a, stream);
+    }
+    ~Scope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(p.b, stream);
+        g_prof.pending.push_back(p);
+    }
+};
+
+void drain_profile()
+{
+    for (const Pending& p : g_prof.pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            g_prof.total_ms[p.slot] += ms;
+            g_prof.launches[p.slot] += 1;
+        }
+        g_prof.pool.push_back(p.a);
+        g_prof.pool.push_back(p.b);
+    }
+    g_prof.pending.clear();
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -93,7 +149,6 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
                            void* workspace, size_t workspace_bytes, unsigned flags, void* stream_)
 {
     const char* who = "dirt_rasterise_forward";
-    (void)flags;
     int rc = check_sizes(who, B, V, F, H, W, C);
     if (rc) return rc;
     if (B == 0) return DIRT_OK;
@@ -108,13 +163,20 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
     auto* recs = reinterpret_cast<dirt::FaceRec*>(ws + w.recs_off);
     auto* boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
 
-    HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+    const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
+    {
+        Scope sc(prof, SLOT_SETUP, stream);
+        HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+    }
     dirt::RasterParams p;
     p.recs = recs; p.boxes = boxes; p.background = background; p.vertex_colors = vertex_colors;
     p.pixels = pixels; p.vis = nullptr;
     p.V = V; p.F = F; p.H = H; p.W = W; p.C = C;
     p.tiles_x = (W + 31) / 32; p.tiles_y = (H + 31) / 32;
-    HIP_TRY(who, dirt::launch_raster(p, B, false, stream));
+    {
+        Scope sc(prof, SLOT_RASTER_FWD, stream);
+        HIP_TRY(who, dirt::launch_raster(p, B, false, stream));
+    }
     g_last_error[0] = 0;
     return DIRT_OK;
 }
@@ -123,7 +185,6 @@ int dirt_rasterise_visibility(const float* vertices, const int32_t* faces, int32
                               int H, int W, void* workspace, size_t workspace_bytes, unsigned flags, void* stream_)
 {
     const char* who = "dirt_rasterise_visibility";
-    (void)flags;
     int rc = check_sizes(who, B, V, F, H, W, 1);
     if (rc) return rc;
     if (B == 0) return DIRT_OK;
@@ -137,13 +198,20 @@ int dirt_rasterise_visibility(const float* vertices, const int32_t* faces, int32
     char* ws = base256(workspace);
     auto* recs = reinterpret_cast<dirt::FaceRec*>(ws + w.recs_off);
     auto* boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
-    HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+    const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
+    {
+        Scope sc(prof, SLOT_SETUP, stream);
+        HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+    }
     dirt::RasterParams p;
     p.recs = recs; p.boxes = boxes; p.background = nullptr; p.vertex_colors = nullptr;
     p.pixels = nullptr; p.vis = face_id;
     p.V = V; p.F = F; p.H = H; p.W = W; p.C = 1;
     p.tiles_x = (W + 31) / 32; p.tiles_y = (H + 31) / 32;
-    HIP_TRY(who, dirt::launch_raster(p, B, true, stream));
+    {
+        Scope sc(prof, SLOT_RASTER_VIS, stream);
+        HIP_TRY(who, dirt::launch_raster(p, B, true, stream));
+    }
     g_last_error[0] = 0;
     return DIRT_OK;
 }
@@ -174,25 +242,56 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
 
     // cudaMemsetAsync x4, csrc/rasterise_grad_egl.cu:244-250 (grad_background and debug_thingy are
     // fully written by the kernel instead)
+    const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
     if (V > 0) {
+        Scope sc(prof, SLOT_MEMSET, stream);
         HIP_TRY(who, hipMemsetAsync(grad_vertices, 0, sizeof(float) * (size_t)B * V * 4, stream));
         HIP_TRY(who, hipMemsetAsync(grad_vertex_colors, 0, sizeof(float) * (size_t)B * V * C, stream));
     }
-    HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+    {
+        Scope sc(prof, SLOT_SETUP, stream);
+        HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+    }
     dirt::RasterParams rp;
     rp.recs = recs; rp.boxes = boxes; rp.background = nullptr; rp.vertex_colors = nullptr;
     rp.pixels = nullptr; rp.vis = vis;
     rp.V = V; rp.F = F; rp.H = H; rp.W = W; rp.C = C;
     rp.tiles_x = (W + 31) / 32; rp.tiles_y = (H + 31) / 32;
-    HIP_TRY(who, dirt::launch_raster(rp, B, true, stream));
+    {
+        Scope sc(prof, SLOT_RASTER_VIS, stream);
+        HIP_TRY(who, dirt::launch_raster(rp, B, true, stream));
+    }
 
     dirt::GradParams gp;
     gp.recs = recs; gp.vis = vis; gp.vertices = vertices; gp.pixels = pixels; gp.grad_pixels = grad_pixels;
     gp.grad_background = grad_background; gp.grad_vertices = grad_vertices;
     gp.grad_vertex_colors = grad_vertex_colors; gp.debug_thingy = debug_thingy;
     gp.B = B; gp.V = V; gp.F = F; gp.H = H; gp.W = W; gp.C = C; gp.flags = flags;
-    HIP_TRY(who, dirt::launch_grad(gp, stream));
+    {
+        Scope sc(prof, SLOT_GRAD, stream);
+        HIP_TRY(who, dirt::launch_grad(gp, stream));
+    }
     g_last_error[0] = 0;
+    return DIRT_OK;
+}
+
+int dirt_profile_count(void) { return SLOT_COUNT; }
+
+const char* dirt_profile_name(int slot) { return (slot >= 0 && slot < SLOT_COUNT) ? kSlotNames[slot] : ""; }
+
+int dirt_profile_read(int slot, double* total_ms, long long* launches)
+{
+    if (slot < 0 || slot >= SLOT_COUNT) return fail(DIRT_E_INVALID_ARGUMENT, "dirt_profile_read: bad slot %d", slot);
+    drain_profile();
+    if (total_ms) *total_ms = g_prof.total_ms[slot];
+    if (launches) *launches = g_prof.launches[slot];
+    return DIRT_OK;
+}
+
+int dirt_profile_reset(void)
+{
+    drain_profile();
+    for (int i = 0; i < SLOT_COUNT; ++i) { g_prof.total_ms[i] = 0; g_prof.launches[i] = 0; }
     return DIRT_OK;
 }
 

@@ -96,7 +96,7 @@ def _require_gpu(*tensors):
     return dev
 
 
-def _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels):
+def _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels, flags=0):
     """`_rasterise_module.rasterise` (dirt/rasterise_ops.py:81-85): the raw forward op, no autograd."""
     lib = _lib.load()
     _check_forward_shapes(background, vertices, vertex_colors, faces, height, width, channels)
@@ -111,7 +111,7 @@ def _op_rasterise(background, vertices, vertex_colors, faces, height, width, cha
         ws = _workspace(dev, nbytes)
         _lib.check(lib.dirt_rasterise_forward(
             background.data_ptr(), vertices.data_ptr(), vertex_colors.data_ptr(), faces.data_ptr(), pixels.data_ptr(),
-            B, V, F, height, width, channels, ws.data_ptr(), ws.numel(), 0, torch.cuda.current_stream(dev).cuda_stream))
+            B, V, F, height, width, channels, ws.data_ptr(), ws.numel(), flags, torch.cuda.current_stream(dev).cuda_stream))
     return pixels
 
 

@@ -46,6 +46,11 @@ extern "C" {
                                     channel reads (csrc/rasterise_grad_egl.cu:119-123,185; SURVEY.md
                                     App. A.3 quirk Q1).  Default (0) reproduces the reference. */
 
+#define DIRT_FLAG_PROFILE 0x100u /* record a HIP-event pair around every kernel this call launches (on the
+                                    call's stream); read the totals with dirt_profile_read.  Replaces the
+                                    reference's compile-time TIME_SECTIONS wall-clock prints
+                                    (csrc/rasterise_egl.cpp:398-405, csrc/rasterise_grad_egl.cpp:479-483). */
+
 /* Limits of this implementation (the reference's limit is the GL max texture size of its atlas). */
 #define DIRT_MAX_DIM 16384
 
@@ -102,6 +107,18 @@ int dirt_rasterise_backward(const float *vertices, const int32_t *faces, const f
 int dirt_rasterise_visibility(const float *vertices, const int32_t *faces, int32_t *face_id, int B, int V,
                               int F, int H, int W, void *workspace, size_t workspace_bytes, unsigned flags,
                               void *stream);
+
+/*
+ * Per-kernel timing (host-side state only).  Slots are the library's kernels; dirt_profile_count()
+ * returns how many there are, dirt_profile_name(i) their names.  dirt_profile_read waits for the
+ * recorded events of calls made with DIRT_FLAG_PROFILE on this thread, adds them to the running
+ * totals and returns total milliseconds and launch count of slot i; dirt_profile_reset clears the
+ * totals.  Returns 0 or DIRT_E_*.
+ */
+int dirt_profile_count(void);
+const char *dirt_profile_name(int slot);
+int dirt_profile_read(int slot, double *total_ms, long long *launches);
+int dirt_profile_reset(void);
 
 #ifdef __cplusplus
 }
