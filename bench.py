@@ -153,10 +153,25 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         oracle.build()
-        cores = os.cpu_count() or 1
-        oracle.set_num_threads(cores)
         one = {k: batch[k][:1] for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
-        oracle.forward(one['background'], one['vertices'], one['vertex_colors'], one['faces'])  # warm
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        # choose the thread count that is fastest on this host (all cores is not: the gradient
+        # scatter contends); one untimed forward+backward per candidate
+        best, cores = None, 1
+        for n in sorted({avail, max(1, avail // 2), 64, 32, 16, 8}):
+            if n > avail:
+                continue
+            oracle.set_num_threads(n)
+            c0 = time.perf_counter()
+            px = oracle.forward(one['background'], one['vertices'], one['vertex_colors'], one['faces'])
+            oracle.backward(one['vertices'], one['faces'], px, one['grad_pixels'])
+            dt = time.perf_counter() - c0
+            if best is None or dt < best:
+                best, cores = dt, n
+        oracle.set_num_threads(cores)
         n_it, t_cpu = 0, 0.0
         while t_cpu < args.cpu_seconds and n_it < 20:
             c0 = time.perf_counter()

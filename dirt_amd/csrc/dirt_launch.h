@@ -29,6 +29,8 @@ struct GradParams {
     float* debug_thingy;       // [B,H,W,3] or nullptr
     int B, V, F, H, W, C;
     unsigned flags;
+    int tiles_x, tiles_y;      // filled by launch_grad
+    int nslots;                // LDS slot-table capacity, filled by launch_grad
 };
 
 hipError_t launch_setup(const float* vertices, const int32_t* faces, FaceRec* recs, FaceBox* boxes, int B, int V,
