@@ -23,9 +23,9 @@ int fail(int code, const char* fmt, ...)
 }
 
 // ---- optional per-kernel HIP-event timing (DIRT_FLAG_PROFILE) ----------------------------------
-enum Slot { SLOT_SETUP = 0, SLOT_RASTER_FWD, SLOT_RASTER_VIS, SLOT_GRAD, SLOT_MEMSET, SLOT_COUNT };
-const char* const kSlotNames[SLOT_COUNT] = {"setup_kernel", "raster_kernel<shade>", "raster_kernel<visibility>",
-                                            "grad_kernel", "memset"};
+enum Slot { SLOT_GEOMETRY = 0, SLOT_RASTER_FWD, SLOT_RASTER_VIS, SLOT_GRAD, SLOT_COUNT };
+const char* const kSlotNames[SLOT_COUNT] = {"geometry (setup+fill)", "raster_kernel<shade>",
+                                            "raster_kernel<visibility>", "grad_kernel"};
 struct Pending {
     hipEvent_t a, b;
     int slot;
@@ -80,20 +80,37 @@ void drain_profile()
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
-    size_t recs_off, boxes_off, vis_off, total;
+    size_t recs_off, boxes_off, ctrs_off, chunk_off, entries_off, big_off, vis_off, total;
 };
 
-// Layout: [FaceRec x B*F | FaceBox x B*F | int32 visibility x B*H*W]
+// Layout: [FaceRec x B*F | FaceBox x B*F | BinCounters x B | chunk histograms | BinEntry x B*4F | BinEntry x B*F |
+//          int32 visibility x B*H*W]
 Workspace carve(int B, int F, int H, int W)
 {
     Workspace w;
     size_t off = 0;
-    w.recs_off = off;  off = align_up(off + (size_t)B * F * sizeof(dirt::FaceRec), 256);
-    w.boxes_off = off; off = align_up(off + (size_t)B * F * sizeof(dirt::FaceBox), 256);
-    w.vis_off = off;   off = align_up(off + (size_t)B * H * W * sizeof(int32_t), 256);
+    w.recs_off = off;    off = align_up(off + (size_t)B * F * sizeof(dirt::FaceRec), 256);
+    w.boxes_off = off;   off = align_up(off + (size_t)B * F * sizeof(dirt::FaceBox), 256);
+    w.ctrs_off = off;    off = align_up(off + (size_t)B * sizeof(dirt::BinCounters), 256);
+    int nchunk, chunk_faces;
+    dirt::chunking(F, nchunk, chunk_faces);
+    w.chunk_off = off;   off = align_up(off + (size_t)B * nchunk * (dirt::MAX_BINS + 1) * sizeof(uint32_t), 256);
+    w.entries_off = off; off = align_up(off + (size_t)B * 4 * F * sizeof(dirt::BinEntry), 256);
+    w.big_off = off;     off = align_up(off + (size_t)B * F * sizeof(dirt::BinEntry), 256);
+    w.vis_off = off;     off = align_up(off + (size_t)B * H * W * sizeof(int32_t), 256);
     w.total = off + 256;
     return w;
 }
+
+struct Carved {
+    dirt::FaceRec* recs;
+    dirt::FaceBox* boxes;
+    dirt::BinCounters* ctrs;
+    uint32_t* chunk_count;
+    dirt::BinEntry* entries;
+    dirt::BinEntry* big;
+    int32_t* vis;
+};
 
 int check_sizes(const char* who, int B, int V, int F, int H, int W, int C)
 {
@@ -130,6 +147,43 @@ inline char* base256(void* workspace)
     return reinterpret_cast<char*>(align_up((size_t)(uintptr_t)workspace, 256));
 }
 
+Carved carved(void* workspace, const Workspace& w)
+{
+    char* ws = base256(workspace);
+    Carved c;
+    c.recs = reinterpret_cast<dirt::FaceRec*>(ws + w.recs_off);
+    c.boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
+    c.ctrs = reinterpret_cast<dirt::BinCounters*>(ws + w.ctrs_off);
+    c.chunk_count = reinterpret_cast<uint32_t*>(ws + w.chunk_off);
+    c.entries = reinterpret_cast<dirt::BinEntry*>(ws + w.entries_off);
+    c.big = reinterpret_cast<dirt::BinEntry*>(ws + w.big_off);
+    c.vis = reinterpret_cast<int32_t*>(ws + w.vis_off);
+    return c;
+}
+
+dirt::GeomParams geom_params(const Carved& c, const float* vertices, const int32_t* faces, int B, int V, int F, int H,
+                             int W)
+{
+    dirt::GeomParams g;
+    g.vertices = vertices; g.faces = faces; g.recs = c.recs; g.boxes = c.boxes; g.ctrs = c.ctrs;
+    g.chunk_count = c.chunk_count; g.entries = c.entries; g.big = c.big;
+    dirt::chunking(F, g.nchunk, g.chunk_faces);
+    g.zero_b = nullptr; g.zero_b_bytes = 0; g.zero_c = nullptr; g.zero_c_bytes = 0;
+    g.B = B; g.V = V; g.F = F; g.H = H; g.W = W;
+    g.grid = dirt::make_bin_grid(H, W);
+    return g;
+}
+
+dirt::RasterParams raster_params(const Carved& c, const dirt::GeomParams& g, int C)
+{
+    dirt::RasterParams p;
+    p.recs = c.recs; p.ctrs = c.ctrs; p.entries = c.entries; p.big = c.big;
+    p.background = nullptr; p.vertex_colors = nullptr; p.pixels = nullptr; p.vis = nullptr;
+    p.V = g.V; p.F = g.F; p.H = g.H; p.W = g.W; p.C = C;
+    p.grid = g.grid; p.tiles_x = 0; p.tiles_y = 0;
+    return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -159,20 +213,15 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
     rc = check_workspace(who, w, workspace, workspace_bytes);
     if (rc) return rc;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    char* ws = base256(workspace);
-    auto* recs = reinterpret_cast<dirt::FaceRec*>(ws + w.recs_off);
-    auto* boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
-
+    const Carved c = carved(workspace, w);
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
+    const dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W);
     {
-        Scope sc(prof, SLOT_SETUP, stream);
-        HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+        Scope sc(prof, SLOT_GEOMETRY, stream);
+        HIP_TRY(who, dirt::launch_geometry(g, stream));
     }
-    dirt::RasterParams p;
-    p.recs = recs; p.boxes = boxes; p.background = background; p.vertex_colors = vertex_colors;
-    p.pixels = pixels; p.vis = nullptr;
-    p.V = V; p.F = F; p.H = H; p.W = W; p.C = C;
-    p.tiles_x = (W + 31) / 32; p.tiles_y = (H + 31) / 32;
+    dirt::RasterParams p = raster_params(c, g, C);
+    p.background = background; p.vertex_colors = vertex_colors; p.pixels = pixels;
     {
         Scope sc(prof, SLOT_RASTER_FWD, stream);
         HIP_TRY(who, dirt::launch_raster(p, B, false, stream));
@@ -195,19 +244,15 @@ int dirt_rasterise_visibility(const float* vertices, const int32_t* faces, int32
     rc = check_workspace(who, w, workspace, workspace_bytes);
     if (rc) return rc;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    char* ws = base256(workspace);
-    auto* recs = reinterpret_cast<dirt::FaceRec*>(ws + w.recs_off);
-    auto* boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
+    const Carved c = carved(workspace, w);
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
+    const dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W);
     {
-        Scope sc(prof, SLOT_SETUP, stream);
-        HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+        Scope sc(prof, SLOT_GEOMETRY, stream);
+        HIP_TRY(who, dirt::launch_geometry(g, stream));
     }
-    dirt::RasterParams p;
-    p.recs = recs; p.boxes = boxes; p.background = nullptr; p.vertex_colors = nullptr;
-    p.pixels = nullptr; p.vis = face_id;
-    p.V = V; p.F = F; p.H = H; p.W = W; p.C = 1;
-    p.tiles_x = (W + 31) / 32; p.tiles_y = (H + 31) / 32;
+    dirt::RasterParams p = raster_params(c, g, 1);
+    p.vis = face_id;
     {
         Scope sc(prof, SLOT_RASTER_VIS, stream);
         HIP_TRY(who, dirt::launch_raster(p, B, true, stream));
@@ -235,32 +280,26 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
     rc = check_workspace(who, w, workspace, workspace_bytes);
     if (rc) return rc;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    char* ws = base256(workspace);
-    auto* recs = reinterpret_cast<dirt::FaceRec*>(ws + w.recs_off);
-    auto* boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
-    auto* vis = reinterpret_cast<int32_t*>(ws + w.vis_off);
-
-    // cudaMemsetAsync x4, csrc/rasterise_grad_egl.cu:244-250 (grad_background and debug_thingy are
-    // fully written by the kernel instead)
+    const Carved c = carved(workspace, w);
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
-    if (V > 0) {
-        Scope sc(prof, SLOT_MEMSET, stream);
-        HIP_TRY(who, hipMemsetAsync(grad_vertices, 0, sizeof(float) * (size_t)B * V * 4, stream));
-        HIP_TRY(who, hipMemsetAsync(grad_vertex_colors, 0, sizeof(float) * (size_t)B * V * C, stream));
-    }
+    dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W);
+    // the cudaMemsetAsync x4 of csrc/rasterise_grad_egl.cu:244-250: grad_vertices / grad_vertex_colors
+    // are cleared by the same launch that clears the bin counters; grad_background and debug_thingy
+    // are fully written by the gradient kernel instead
+    g.zero_b = grad_vertices;      g.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
+    g.zero_c = grad_vertex_colors; g.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
     {
-        Scope sc(prof, SLOT_SETUP, stream);
-        HIP_TRY(who, dirt::launch_setup(vertices, faces, recs, boxes, B, V, F, H, W, stream));
+        Scope sc(prof, SLOT_GEOMETRY, stream);
+        HIP_TRY(who, dirt::launch_geometry(g, stream));
     }
-    dirt::RasterParams rp;
-    rp.recs = recs; rp.boxes = boxes; rp.background = nullptr; rp.vertex_colors = nullptr;
-    rp.pixels = nullptr; rp.vis = vis;
-    rp.V = V; rp.F = F; rp.H = H; rp.W = W; rp.C = C;
-    rp.tiles_x = (W + 31) / 32; rp.tiles_y = (H + 31) / 32;
+    dirt::RasterParams rp = raster_params(c, g, C);
+    rp.vis = c.vis;
     {
         Scope sc(prof, SLOT_RASTER_VIS, stream);
         HIP_TRY(who, dirt::launch_raster(rp, B, true, stream));
     }
+    int32_t* vis = c.vis;
+    auto* recs = c.recs;
 
     dirt::GradParams gp;
     gp.recs = recs; gp.vis = vis; gp.vertices = vertices; gp.pixels = pixels; gp.grad_pixels = grad_pixels;

@@ -6,15 +6,59 @@
 
 namespace dirt {
 
+constexpr int MAX_BINS = 256;
+
+// Coarse binning grid: square bins of (1 << shift) pixels, shift >= 7, bins_x * bins_y <= MAX_BINS.
+struct BinGrid {
+    int shift, bins_x, bins_y;
+};
+
+// One entry of a bin's face list (also of the per-scene "big" list), 16 bytes.
+struct alignas(16) BinEntry {
+    FaceBox box;
+    int32_t face;
+    uint32_t pad;
+};
+static_assert(sizeof(BinEntry) == 16, "BinEntry must be 16 bytes");
+
+// Per-scene bin directory, written by fill_kernel (chunk 0) for the raster kernel.
+struct alignas(16) BinCounters {
+    uint32_t count[MAX_BINS];   // faces per bin
+    uint32_t start[MAX_BINS];   // first entry of the bin's segment (exclusive prefix of count)
+    uint32_t big_count;         // faces touching more than 4 bins
+    uint32_t pad[3];
+};
+
+struct GeomParams {
+    const float* vertices;  // [B,V,4]
+    const int32_t* faces;   // [B,F,3]
+    FaceRec* recs;          // [B*F]
+    FaceBox* boxes;         // [B*F]
+    BinCounters* ctrs;      // [B]
+    uint32_t* chunk_count;  // [B][nchunk][MAX_BINS + 1] per-chunk bin histogram (+ big faces)
+    BinEntry* entries;      // [B][4F]
+    BinEntry* big;          // [B][F]
+    void* zero_b;           // optional extra buffers cleared by the same launch (multiples of 16 bytes)
+    size_t zero_b_bytes;
+    void* zero_c;
+    size_t zero_c_bytes;
+    int B, V, F, H, W;
+    int nchunk, chunk_faces;  // faces are processed in nchunk contiguous chunks per scene
+    BinGrid grid;
+};
+
 struct RasterParams {
     const FaceRec* recs;         // [B*F] set-up records (workspace)
-    const FaceBox* boxes;        // [B*F] bounding boxes (workspace)
+    const BinCounters* ctrs;     // [B]
+    const BinEntry* entries;     // [B][4F] per-bin face lists
+    const BinEntry* big;         // [B][F] faces touching many bins
     const float* background;     // [B,H,W,C]
     const float* vertex_colors;  // [B,V,C]
     float* pixels;               // [B,H,W,C]
     int32_t* vis;                // [B,H,W] visibility export (MODE 1)
     int V, F, H, W, C;
-    int tiles_x, tiles_y;
+    BinGrid grid;
+    int tiles_x, tiles_y;        // filled by launch_raster
 };
 
 struct GradParams {
@@ -33,8 +77,9 @@ struct GradParams {
     int nslots;                // LDS slot-table capacity, filled by launch_grad
 };
 
-hipError_t launch_setup(const float* vertices, const int32_t* faces, FaceRec* recs, FaceBox* boxes, int B, int V,
-                        int F, int H, int W, hipStream_t stream);
+BinGrid make_bin_grid(int H, int W);
+void chunking(int F, int& nchunk, int& chunk_faces);
+hipError_t launch_geometry(const GeomParams& g, hipStream_t stream);
 hipError_t launch_raster(const RasterParams& p, int B, bool visibility_only, hipStream_t stream);
 hipError_t launch_grad(const GradParams& p, hipStream_t stream);
 

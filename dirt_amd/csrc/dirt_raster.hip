@@ -7,16 +7,18 @@
 //   * upload_background / download_pixels           (csrc/rasterise_egl.cu:10-38,65-91): there is no
 //     RGBA32F atlas; tiles read `background` and write `pixels` in place, top row first.
 //
-// Structure of raster_kernel (one 256-thread workgroup = one 32x32 pixel tile of one scene):
-//   scan   : the four waves stride over the scene's FaceBox array (8 B/face, coalesced) and append
-//            the faces whose box touches the tile to an LDS list (wave-aggregated LDS atomic);
-//   raster : wave w owns the 8-row band w of the tile as four 8x8 blocks, one pixel per lane.
-//            Per block, lanes first test 64 list entries at a time against the block rectangle
-//            (ballot -> 64-bit survivor mask); survivors are visited with a scalar bit-scan, their
-//            FaceRec fetched with wave-uniform (scalar) loads so the nine f64 edge coefficients sit
-//            in SGPRs; each lane evaluates the three edge functions at its pixel centre exactly as
-//            the specification writes them, then depth, then a (z24, face) lexicographic min held
-//            in registers -- no LDS or global atomics, and the result is independent of list order;
+// Structure of raster_kernel (one 1024-thread workgroup = one 32x32 pixel tile of one scene; each of
+// its 16 waves owns one 8x8 block, one pixel per lane):
+//   scan   : the waves stride over the scene's FaceBox array (8 B/face, coalesced) and append the
+//            faces whose box touches the tile to an LDS list (wave-aggregated LDS atomic), together
+//            with a 16-bit mask of the blocks the box touches;
+//   raster : each wave tests 64 list entries at a time against its block bit (ballot -> 64-bit
+//            survivor mask); survivors are visited with a scalar bit-scan, their record fetched with
+//            wave-uniform (scalar) loads so the nine f64 edge coefficients sit in SGPRs, the next
+//            survivor's loads in flight while the current one is evaluated; each lane evaluates the
+//            three edge functions at its pixel centre exactly as the specification writes them,
+//            then depth, then a (z24, face) lexicographic min held in registers -- no LDS or global
+//            atomics, and the result is independent of list order;
 //   shade  : the winner's record is re-read per pixel, barycentrics and all C channels are
 //            interpolated once, and the HWC pixel is written (background copied where uncovered).
 #include "dirt_device.h"
@@ -24,48 +26,164 @@
 
 namespace dirt {
 
-__global__ __launch_bounds__(256) void setup_kernel(const float* __restrict__ vertices,
-                                                    const int32_t* __restrict__ faces, FaceRec* __restrict__ recs,
-                                                    FaceBox* __restrict__ boxes, int B, int V, int F, int H, int W)
+// ---- binning ---------------------------------------------------------------------------------
+// The frame is cut into at most MAX_BINS square bins of 2^shift pixels (>= 128, so a raster tile
+// never straddles two bins).  Two kernels build, per scene, an exact-size list of the faces touching
+// each bin -- the replacement for the GL driver's own binning hardware -- without a single global
+// atomic and without any buffer that needs clearing:
+//   setup_kernel : the scene's faces are cut into `nchunk` contiguous chunks, one 256-thread
+//                  workgroup each.  Per face: set-up record, bounding box, and an LDS count in every
+//                  bin the box touches (faces touching more than 4 bins are counted for the scene's
+//                  "big" list, which every tile reads, so the bin lists hold <= 4F entries in total).
+//                  The chunk's histogram row is stored to chunk_count[chunk][bin].
+//   fill_kernel  : same chunks.  Column sums of the count matrix give each bin's size, an exclusive
+//                  prefix over bins gives its segment, the partial column sum over earlier chunks
+//                  gives this chunk's offset inside the segment; faces then claim slots with LDS
+//                  cursors.  Chunk 0 publishes count / start / big_count for the raster kernel.
+// List order inside a chunk is whatever the LDS atomics produce; visibility does not depend on it.
+
+__device__ __forceinline__ bool bin_range(const FaceBox& box, const BinGrid& grid, int& bx0, int& bx1, int& by0, int& by1)
 {
-    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= (long long)B * F) return;
-    const int ib = (int)(n / F);
-    FaceRec rec;
-    FaceBox box;
-    const bool ok = setup_face(vertices + (size_t)ib * V * 4, V, faces + (size_t)n * 3, H, W, rec, box);
-    if (ok) {
-        recs[n] = rec;
-    } else {
-        recs[n].flags = 0;
-        box.i_min = 32767; box.i_max = -32768; box.r_min = 32767; box.r_max = -32768;
-    }
-    boxes[n] = box;
+    bx0 = box.i_min >> grid.shift; bx1 = box.i_max >> grid.shift;
+    by0 = box.r_min >> grid.shift; by1 = box.r_max >> grid.shift;
+    return (bx1 - bx0 + 1) * (by1 - by0 + 1) <= 4;  // false: the face goes on the big list
 }
 
-constexpr int TILE = 32;        // tile edge in pixels
-constexpr int BLK = 8;          // block edge: one wave = one 8x8 block at a time
-constexpr int LIST_CAP = 2048;  // faces scanned (and at most listed) per round
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ b, size_t nb, uint32_t* __restrict__ c, size_t nc)
+{
+    // clears caller buffers of any alignment in 4-byte units (the gradients of the backward pass)
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += stride) c[i] = 0u;
+}
 
-struct ListEntry {
-    int32_t face;
-    int16_t i_min, i_max, r_min, r_max;
+__global__ __launch_bounds__(256) void setup_kernel(GeomParams g)
+{
+    __shared__ uint32_t s_cnt[MAX_BINS + 1];  // [MAX_BINS] = big faces
+    const int ib = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    s_cnt[tid] = 0;
+    if (tid == 0) s_cnt[MAX_BINS] = 0;
+    __syncthreads();
+    const int f0 = chunk * g.chunk_faces, f1 = min(g.F, f0 + g.chunk_faces);
+    const float* __restrict__ verts = g.vertices + (size_t)ib * g.V * 4;
+    for (int f = f0 + tid; f < f1; f += 256) {
+        const size_t n = (size_t)ib * g.F + f;
+        FaceRec rec;
+        FaceBox box;
+        if (setup_face(verts, g.V, g.faces + n * 3, g.H, g.W, rec, box)) {
+            g.recs[n] = rec;
+            int bx0, bx1, by0, by1;
+            if (bin_range(box, g.grid, bx0, bx1, by0, by1)) {
+                for (int by = by0; by <= by1; ++by)
+                    for (int bx = bx0; bx <= bx1; ++bx) atomicAdd(&s_cnt[by * g.grid.bins_x + bx], 1u);
+            } else {
+                atomicAdd(&s_cnt[MAX_BINS], 1u);
+            }
+        } else {
+            g.recs[n].flags = 0;
+            box.i_min = 32767; box.i_max = -32768; box.r_min = 32767; box.r_max = -32768;
+        }
+        g.boxes[n] = box;
+    }
+    __syncthreads();
+    uint32_t* __restrict__ row = g.chunk_count + ((size_t)ib * g.nchunk + chunk) * (MAX_BINS + 1);
+    row[tid] = s_cnt[tid];
+    if (tid == 0) row[MAX_BINS] = s_cnt[MAX_BINS];
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(GeomParams g)
+{
+    __shared__ uint32_t s_base[MAX_BINS + 1];  // first slot of this chunk in each bin's segment ([MAX_BINS]: big list)
+    __shared__ uint32_t s_cur[MAX_BINS + 1];
+    __shared__ uint32_t s_wave[4];
+    const int ib = blockIdx.y, chunk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t* __restrict__ mat = g.chunk_count + (size_t)ib * g.nchunk * (MAX_BINS + 1);
+
+    // column sums over all chunks (bin sizes) and over the chunks before this one
+    uint32_t total = 0, before = 0;
+    for (int c = 0; c < g.nchunk; ++c) {
+        const uint32_t v = mat[(size_t)c * (MAX_BINS + 1) + tid];
+        total += v;
+        if (c < chunk) before += v;
+    }
+    uint32_t incl = total;  // exclusive prefix of the bin sizes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    const uint32_t start = off + incl - total;
+    s_base[tid] = start + before;
+    s_cur[tid] = 0;
+    BinCounters* __restrict__ ctr = g.ctrs + ib;
+    if (chunk == 0) { ctr->count[tid] = total; ctr->start[tid] = start; }
+    if (tid == 0) {
+        uint32_t btotal = 0, bbefore = 0;
+        for (int c = 0; c < g.nchunk; ++c) {
+            const uint32_t v = mat[(size_t)c * (MAX_BINS + 1) + MAX_BINS];
+            btotal += v;
+            if (c < chunk) bbefore += v;
+        }
+        s_base[MAX_BINS] = bbefore;
+        s_cur[MAX_BINS] = 0;
+        if (chunk == 0) ctr->big_count = btotal;
+    }
+    __syncthreads();
+
+    const int f0 = chunk * g.chunk_faces, f1 = min(g.F, f0 + g.chunk_faces);
+    BinEntry* __restrict__ out = g.entries + (size_t)ib * 4 * g.F;
+    BinEntry* __restrict__ big = g.big + (size_t)ib * g.F;
+    for (int f = f0 + tid; f < f1; f += 256) {
+        BinEntry e;
+        e.box = g.boxes[(size_t)ib * g.F + f];
+        if (e.box.i_min > e.box.i_max) continue;  // culled at set-up
+        e.face = f; e.pad = 0;
+        int bx0, bx1, by0, by1;
+        if (bin_range(e.box, g.grid, bx0, bx1, by0, by1)) {
+            for (int by = by0; by <= by1; ++by)
+                for (int bx = bx0; bx <= bx1; ++bx) {
+                    const int b = by * g.grid.bins_x + bx;
+                    out[s_base[b] + atomicAdd(&s_cur[b], 1u)] = e;
+                }
+        } else {
+            big[s_base[MAX_BINS] + atomicAdd(&s_cur[MAX_BINS], 1u)] = e;
+        }
+    }
+}
+
+constexpr int TILE_W = 32;        // tile = 32 x 16 pixels
+constexpr int TILE_H = 16;
+constexpr int BLK = 8;            // block edge: one wave = one 8x8 block, one pixel per lane
+constexpr int RTHREADS = 512;     // 8 waves = the 4x2 blocks of a tile
+constexpr int LIST_CAP = 2048;    // bin entries scanned (and at most listed) per round
+
+// The part of a FaceRec the coverage / depth loop needs (its first 104 bytes).  Loaded through a
+// wave-uniform address, so it is fetched with scalar loads and lives in SGPRs.
+struct RecCore {
+    double coef[9];
+    double zs[3];
+    uint32_t flags;
+    uint32_t pad;
 };
+static_assert(sizeof(RecCore) == 104, "RecCore is the head of FaceRec");
 
-// Per-candidate work of one wave on one 8x8 block: coverage + depth + visibility update.
-// `rec` is wave-uniform: the compiler keeps it in SGPRs.
-__device__ __forceinline__ void raster_candidate(const FaceRec* __restrict__ rec, int face, double px, double py,
+// Per-candidate work of one wave on its 8x8 block: coverage + depth + visibility update.
+__device__ __forceinline__ void raster_candidate(const RecCore& rec, int face, double px, double py,
                                                  uint32_t& zbest, int32_t& fbest)
 {
-    const uint32_t flags = rec->flags;
     double Fk[3];
-    edge_eval(rec->coef, px, py, Fk);
-    const bool c0 = (Fk[0] >= 0.0) != ((flags & 1u) != 0);
-    const bool c1 = (Fk[1] >= 0.0) != ((flags & 2u) != 0);
-    const bool c2 = (Fk[2] >= 0.0) != ((flags & 4u) != 0);
+    edge_eval(rec.coef, px, py, Fk);
+    const bool c0 = (Fk[0] >= 0.0) != ((rec.flags & 1u) != 0);
+    const bool c1 = (Fk[1] >= 0.0) != ((rec.flags & 2u) != 0);
+    const bool c2 = (Fk[2] >= 0.0) != ((rec.flags & 4u) != 0);
     if (c0 && c1 && c2) {
-        const double t = Fk[2] * rec->zs[2];
-        const double zn = fma(Fk[0], rec->zs[0], fma(Fk[1], rec->zs[1], t));
+        const double t = Fk[2] * rec.zs[2];
+        const double zn = fma(Fk[0], rec.zs[0], fma(Fk[1], rec.zs[1], t));
         if (zn >= -1.0 && zn <= 1.0) {
             const uint32_t z24 = (uint32_t)rint(fma(zn, 8388607.5, 8388607.5));
             // GL_LESS against the stored depth; equal depth keeps the lower face index, which is
@@ -75,46 +193,60 @@ __device__ __forceinline__ void raster_candidate(const FaceRec* __restrict__ rec
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void raster_kernel(RasterParams p)
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8); give every XCD a
+// contiguous run of tiles (a band of tile rows) so neighbouring tiles, which share faces, hit the
+// same L2.  Bijective for any tile count.  Speed only; nothing depends on placement.
+__device__ __forceinline__ int xcd_tile(int b, int ntiles)
 {
-    __shared__ ListEntry s_list[LIST_CAP];
+    const int x = b & 7, j = b >> 3;
+    const int q = ntiles >> 3, rem = ntiles & 7;
+    return x * q + min(x, rem) + j;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
+{
+    __shared__ int32_t s_face[LIST_CAP];
+    __shared__ uint8_t s_mask[LIST_CAP];  // bit (4*by + bx): the face's box touches block (bx, by) of the tile
     __shared__ uint32_t s_count;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int ib = blockIdx.y;
-    const int tile = blockIdx.x;
-    const int tx0 = (tile % p.tiles_x) * TILE;
-    const int tr0 = (tile / p.tiles_x) * TILE;
-    const int tx1 = tx0 + TILE - 1, tr1 = tr0 + TILE - 1;
+    const int tile = xcd_tile(blockIdx.x, p.tiles_x * p.tiles_y);
+    const int tx0 = (tile % p.tiles_x) * TILE_W;
+    const int tr0 = (tile / p.tiles_x) * TILE_H;
+    const int tx1 = tx0 + TILE_W - 1, tr1 = tr0 + TILE_H - 1;
 
     const FaceRec* __restrict__ recs = p.recs + (size_t)ib * p.F;
-    const FaceBox* __restrict__ boxes = p.boxes + (size_t)ib * p.F;
+    const BinCounters* __restrict__ ctr = p.ctrs + ib;
+    const int bin = (tr0 >> p.grid.shift) * p.grid.bins_x + (tx0 >> p.grid.shift);
+    const int n_bin = (int)ctr->count[bin];
+    const int n_all = n_bin + (int)ctr->big_count;
+    const BinEntry* __restrict__ bin_entries = p.entries + (size_t)ib * 4 * p.F + ctr->start[bin];
+    const BinEntry* __restrict__ big_entries = p.big + (size_t)ib * p.F;
 
-    // this lane's pixel inside block `blk` of its wave's band: column bx(blk)+lx, row r
-    const int lx = lane & 7, ly = lane >> 3;
-    const int r = tr0 + wave * BLK + ly;
+    // this wave's block and this lane's pixel
+    const int x = tx0 + (wave & 3) * BLK + (lane & 7);
+    const int r = tr0 + (wave >> 2) * BLK + (lane >> 3);
+    const double px = (double)x + 0.5;
     const double py = (double)(p.H - 1 - r) + 0.5;
-    const int br0 = tr0 + wave * BLK, br1 = br0 + BLK - 1;
 
-    uint32_t zbest[4];
-    int32_t fbest[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { zbest[k] = Z24_CLEAR; fbest[k] = -1; }  // -1: a tie with the cleared depth never wins
+    uint32_t zbest = Z24_CLEAR;
+    int32_t fbest = -1;  // -1: a tie with the cleared depth never wins
 
-    for (int round = 0; round < p.F; round += LIST_CAP) {
+    for (int round = 0; round < n_all; round += LIST_CAP) {
         if (tid == 0) s_count = 0;
         __syncthreads();
-        const int round_end = min(p.F, round + LIST_CAP);
-        for (int base = round; base < round_end; base += 256) {
-            const int f = base + tid;
+        const int round_end = min(n_all, round + LIST_CAP);
+        for (int base = round; base < round_end; base += RTHREADS) {
+            const int e = base + tid;
             bool hit = false;
-            FaceBox bb;
-            if (f < round_end) {
-                bb = boxes[f];
-                hit = bb.i_min <= tx1 && bb.i_max >= tx0 && bb.r_min <= tr1 && bb.r_max >= tr0;
+            BinEntry en;
+            if (e < round_end) {
+                en = e < n_bin ? bin_entries[e] : big_entries[e - n_bin];
+                hit = en.box.i_min <= tx1 && en.box.i_max >= tx0 && en.box.r_min <= tr1 && en.box.r_max >= tr0;
             }
             const unsigned long long m = __ballot(hit);
             if (m) {
@@ -124,114 +256,152 @@ __global__ __launch_bounds__(256) void raster_kernel(RasterParams p)
                 off = __shfl(off, leader);
                 if (hit) {
                     const uint32_t slot = off + __popcll(m & ((1ull << lane) - 1ull));
-                    ListEntry e;
-                    e.face = f; e.i_min = bb.i_min; e.i_max = bb.i_max; e.r_min = bb.r_min; e.r_max = bb.r_max;
-                    s_list[slot] = e;
+                    const int bx0 = max(en.box.i_min - tx0, 0) >> 3, bx1 = min(en.box.i_max - tx0, TILE_W - 1) >> 3;
+                    const int by0 = max(en.box.r_min - tr0, 0) >> 3, by1 = min(en.box.r_max - tr0, TILE_H - 1) >> 3;
+                    const uint32_t rowbits = ((2u << bx1) - (1u << bx0)) & 0xFu;
+                    uint32_t mask = 0;
+                    for (int by = by0; by <= by1; ++by) mask |= rowbits << (4 * by);
+                    s_face[slot] = en.face;
+                    s_mask[slot] = (uint8_t)mask;
                 }
             }
         }
         __syncthreads();
         const int n = (int)s_count;
 
-#pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            const int bx0 = tx0 + blk * BLK, bx1 = bx0 + BLK - 1;
-            const double px = (double)(bx0 + lx) + 0.5;
-            for (int cb = 0; cb < n; cb += 64) {
-                const int idx = cb + lane;
-                bool hit = false;
-                int32_t myface = 0;
-                if (idx < n) {
-                    const ListEntry e = s_list[idx];
-                    myface = e.face;
-                    hit = e.i_min <= bx1 && e.i_max >= bx0 && e.r_min <= br1 && e.r_max >= br0;
-                }
-                unsigned long long m = __ballot(hit);
-                while (m) {
-                    const int k = __ffsll((long long)m) - 1;
+        for (int cb = 0; cb < n; cb += 64) {
+            const int idx = cb + lane;
+            bool hit = false;
+            int32_t myface = 0;
+            if (idx < n) {
+                myface = s_face[idx];
+                hit = ((s_mask[idx] >> wave) & 1u) != 0;
+            }
+            unsigned long long m = __ballot(hit);
+            if (m == 0) continue;
+            // software pipeline over the survivors: the next record's scalar loads are in flight
+            // while the current one is evaluated
+            int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            int face = __builtin_amdgcn_readlane(myface, k);
+            RecCore cur = *reinterpret_cast<const RecCore*>(recs + face);
+            while (true) {
+                const bool more = m != 0;
+                int nface = face;
+                if (more) {
+                    k = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    const int face = __builtin_amdgcn_readlane(myface, k);
-                    raster_candidate(recs + face, face, px, py, zbest[blk], fbest[blk]);
+                    nface = __builtin_amdgcn_readlane(myface, k);
                 }
+                const RecCore nxt = *reinterpret_cast<const RecCore*>(recs + nface);
+                raster_candidate(cur, face, px, py, zbest, fbest);
+                if (!more) break;
+                cur = nxt;
+                face = nface;
             }
         }
         __syncthreads();
     }
 
     // ---- resolve: shade (MODE 0) or export the visibility buffer (MODE 1) ----
-    if (r >= p.H) return;
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
-        const int x = tx0 + blk * BLK + lx;
-        if (x >= p.W) continue;
-        const size_t pix = ((size_t)ib * p.H + r) * p.W + x;
-        const int32_t f = fbest[blk];
-        if (MODE == 1) {
-            p.vis[pix] = f;
-            continue;
-        }
-        const int C = p.C;
-        float* __restrict__ out = p.pixels + pix * C;
-        if (f < 0) {
-            const float* __restrict__ bg = p.background + pix * C;
-            if ((C & 3) == 0) {
-                for (int c = 0; c < C; c += 4)
-                    *reinterpret_cast<float4*>(out + c) = *reinterpret_cast<const float4*>(bg + c);
-            } else {
-                for (int c = 0; c < C; ++c) out[c] = bg[c];
-            }
-            continue;
-        }
-        const FaceRec* __restrict__ rec = recs + f;
-        double cf[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) cf[k] = rec->coef[k];
-        double Fk[3];
-        edge_eval(cf, (double)x + 0.5, py, Fk);
-        float b[3], cw;
-        bary_eval(Fk, rec->flags, rec->inv_det, b, cw);
-        const float* __restrict__ cols = p.vertex_colors + (size_t)ib * p.V * C;
-        const float* __restrict__ c0 = cols + (size_t)rec->vid[0] * C;
-        const float* __restrict__ c1 = cols + (size_t)rec->vid[1] * C;
-        const float* __restrict__ c2 = cols + (size_t)rec->vid[2] * C;
+    if (r >= p.H || x >= p.W) return;
+    const size_t pix = ((size_t)ib * p.H + r) * p.W + x;
+    const int32_t f = fbest;
+    if (MODE == 1) {
+        p.vis[pix] = f;
+        return;
+    }
+    const int C = p.C;
+    float* __restrict__ out = p.pixels + pix * C;
+    if (f < 0) {
+        const float* __restrict__ bg = p.background + pix * C;
         if ((C & 3) == 0) {
-            for (int c = 0; c < C; c += 4) {
-                const float4 u0 = *reinterpret_cast<const float4*>(c0 + c);
-                const float4 u1 = *reinterpret_cast<const float4*>(c1 + c);
-                const float4 u2 = *reinterpret_cast<const float4*>(c2 + c);
-                float4 o;
-                o.x = fmaf(b[2], u2.x, fmaf(b[1], u1.x, b[0] * u0.x));
-                o.y = fmaf(b[2], u2.y, fmaf(b[1], u1.y, b[0] * u0.y));
-                o.z = fmaf(b[2], u2.z, fmaf(b[1], u1.z, b[0] * u0.z));
-                o.w = fmaf(b[2], u2.w, fmaf(b[1], u1.w, b[0] * u0.w));
-                *reinterpret_cast<float4*>(out + c) = o;
-            }
+            for (int c = 0; c < C; c += 4)
+                *reinterpret_cast<float4*>(out + c) = *reinterpret_cast<const float4*>(bg + c);
         } else {
-            for (int c = 0; c < C; ++c) out[c] = fmaf(b[2], c2[c], fmaf(b[1], c1[c], b[0] * c0[c]));
+            for (int c = 0; c < C; ++c) out[c] = bg[c];
         }
+        return;
+    }
+    const FaceRec* __restrict__ rec = recs + f;
+    double cf[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cf[k] = rec->coef[k];
+    double Fk[3];
+    edge_eval(cf, px, py, Fk);
+    float b[3], cw;
+    bary_eval(Fk, rec->flags, rec->inv_det, b, cw);
+    const float* __restrict__ cols = p.vertex_colors + (size_t)ib * p.V * C;
+    const float* __restrict__ c0 = cols + (size_t)rec->vid[0] * C;
+    const float* __restrict__ c1 = cols + (size_t)rec->vid[1] * C;
+    const float* __restrict__ c2 = cols + (size_t)rec->vid[2] * C;
+    if ((C & 3) == 0) {
+        for (int c = 0; c < C; c += 4) {
+            const float4 u0 = *reinterpret_cast<const float4*>(c0 + c);
+            const float4 u1 = *reinterpret_cast<const float4*>(c1 + c);
+            const float4 u2 = *reinterpret_cast<const float4*>(c2 + c);
+            float4 o;
+            o.x = fmaf(b[2], u2.x, fmaf(b[1], u1.x, b[0] * u0.x));
+            o.y = fmaf(b[2], u2.y, fmaf(b[1], u1.y, b[0] * u0.y));
+            o.z = fmaf(b[2], u2.z, fmaf(b[1], u1.z, b[0] * u0.z));
+            o.w = fmaf(b[2], u2.w, fmaf(b[1], u1.w, b[0] * u0.w));
+            *reinterpret_cast<float4*>(out + c) = o;
+        }
+    } else {
+        for (int c = 0; c < C; ++c) out[c] = fmaf(b[2], c2[c], fmaf(b[1], c1[c], b[0] * c0[c]));
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 
-hipError_t launch_setup(const float* vertices, const int32_t* faces, FaceRec* recs, FaceBox* boxes, int B, int V,
-                        int F, int H, int W, hipStream_t stream)
+hipError_t launch_geometry(const GeomParams& g, hipStream_t stream)
 {
-    const long long n = (long long)B * F;
-    if (n == 0) return hipSuccess;
-    const unsigned grid = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(setup_kernel, dim3(grid), dim3(256), 0, stream, vertices, faces, recs, boxes, B, V, F, H, W);
+    if (g.zero_b_bytes || g.zero_c_bytes) {
+        const size_t nb = g.zero_b_bytes / 4, nc = g.zero_c_bytes / 4;
+        const size_t most = nb > nc ? nb : nc;
+        unsigned grid = (unsigned)((most + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<uint32_t*>(g.zero_b), nb,
+                           reinterpret_cast<uint32_t*>(g.zero_c), nc);
+    }
+    if (g.B == 0) return hipGetLastError();
+    // also with F == 0: fill publishes the (all-zero) directory the raster kernel reads
+    const dim3 grid((unsigned)g.nchunk, (unsigned)g.B);
+    hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(fill_kernel, grid, dim3(256), 0, stream, g);
     return hipGetLastError();
 }
 
-hipError_t launch_raster(const RasterParams& p, int B, bool visibility_only, hipStream_t stream)
+void chunking(int F, int& nchunk, int& chunk_faces)
+{
+    // <= 256 chunks of >= 256 faces: the count matrix stays small enough for every fill workgroup
+    // to read all of it
+    chunk_faces = 256;
+    if ((long long)chunk_faces * 256 < F) chunk_faces = (F + 255) / 256;
+    nchunk = F > 0 ? (F + chunk_faces - 1) / chunk_faces : 1;
+}
+
+BinGrid make_bin_grid(int H, int W)
+{
+    BinGrid g;
+    g.shift = 7;
+    while (((W + (1 << g.shift) - 1) >> g.shift) * ((H + (1 << g.shift) - 1) >> g.shift) > MAX_BINS) ++g.shift;
+    g.bins_x = (W + (1 << g.shift) - 1) >> g.shift;
+    g.bins_y = (H + (1 << g.shift) - 1) >> g.shift;
+    return g;
+}
+
+hipError_t launch_raster(const RasterParams& p_in, int B, bool visibility_only, hipStream_t stream)
 {
     if (B == 0) return hipSuccess;
+    RasterParams p = p_in;
+    p.tiles_x = (p.W + TILE_W - 1) / TILE_W;
+    p.tiles_y = (p.H + TILE_H - 1) / TILE_H;
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)B);
     if (visibility_only)
-        hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(RTHREADS), 0, stream, p);
     else
-        hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(RTHREADS), 0, stream, p);
     return hipGetLastError();
 }
 
