@@ -157,11 +157,14 @@ __device__ __forceinline__ void fix_add(unsigned long long* acc, const Target& t
 
 __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
 {
-    __shared__ float s_pix[3][PH][PW];                            // the current group's channels of `pixels`, edge clamped
+    __shared__ float s_pix[3][PH][PW];                               // the current group's channels of `pixels`, edge clamped
     __shared__ unsigned long long s_acc[MAX_SLOTS * NVAL * COPIES];  // fixed-point partial sums
-    __shared__ int32_t s_vis[PH][VW];
-    __shared__ int32_t s_key[MAX_SLOTS];
-    __shared__ uint32_t s_max[2];                                 // largest |position| / |colour| contribution (float bits)
+    __shared__ float4 s_frag[PH][VW];                                // (b0,b1,b2,clip_w) of every pixel of the halo'd tile
+    __shared__ int32_t s_vis[PH][VW];                                // its front-most face
+    __shared__ int16_t s_slot[PH][VW];                               // and that face's slot (-1 none, -2 table full)
+    __shared__ int32_t s_key[MAX_SLOTS];                             // slot -> face
+    __shared__ int32_t s_vid[MAX_SLOTS][3];                          // slot -> the face's vertex indices
+    __shared__ uint32_t s_max[2];                                    // largest |position| / |colour| contribution (float bits)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -181,22 +184,45 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
     float* __restrict__ grad_vertices = p.grad_vertices + (size_t)iib * p.V * 4;
     float* __restrict__ grad_vertex_colors = p.grad_vertex_colors + (size_t)iib * p.V * C;
 
-    // ---- init: slot table, accumulators, visibility tile with halo (clamped reads; the halo is
-    //      only consulted for interior pixels, whose neighbours are inside the frame) ----
+    // ---- init ----
     for (int i = tid; i < MAX_SLOTS; i += GTHREADS) s_key[i] = -1;
     for (int i = tid; i < MAX_SLOTS * NVAL * COPIES; i += GTHREADS) s_acc[i] = 0ull;
     if (tid < 2) s_max[tid] = 0u;
+    __syncthreads();
+
+    // ---- phase A: the visibility "surfaces" of the tile + 1-pixel halo, what the backward fragment
+    //      shader writes (csrc/shaders.cpp:64-77) over the clear values of
+    //      csrc/rasterise_grad_egl.cpp:442-445.  Halo positions outside the frame are clamped; they
+    //      are only ever consulted for interior pixels, whose neighbours are inside the frame. ----
     for (int i = tid; i < PH * VW; i += GTHREADS) {
         const int vy = i / VW, vx = i - vy * VW;
         const int rr = min(max(tr0 + vy - 1, 0), H - 1), xx = min(max(tx0 + vx - 1, 0), W - 1);
-        s_vis[vy][vx] = vis[(size_t)rr * W + xx];
+        const int32_t face = vis[(size_t)rr * W + xx];
+        float4 fr = make_float4(-1.f, -1.f, -1.f, INFINITY);
+        int slot = -1;
+        if (face >= 0) {
+            const Frag f = frag_eval(recs, face, xx, rr, H);
+            fr = make_float4(f.b[0], f.b[1], f.b[2], f.w);
+            slot = slot_insert(s_key, MAX_SLOTS, face);
+            if (slot < 0) slot = -2;
+        }
+        s_vis[vy][vx] = face;
+        s_frag[vy][vx] = fr;
+        s_slot[vy][vx] = (int16_t)slot;
     }
     __syncthreads();
+    if (tid < MAX_SLOTS) {
+        const int32_t face = s_key[tid];
+        if (face >= 0) {
+            s_vid[tid][0] = recs[face].vid[0]; s_vid[tid][1] = recs[face].vid[1]; s_vid[tid][2] = recs[face].vid[2];
+        }
+    }
+    // (the first group's staging barrier publishes s_vid)
 
     // ---- this lane's pixel ----
-    const int px_l = (wave & 3) * 8 + (lane & 7), py_l = (wave >> 2) * 8 + (lane >> 3);  // position inside the tile
-    const int x_in_frame = tx0 + px_l;
-    const int y_in_frame = tr0 + py_l;  // tensor row (top row first)
+    const int px_l = (wave & 3) * 8 + (lane & 7) + 1, py_l = (wave >> 2) * 8 + (lane >> 3) + 1;  // in the halo'd tile
+    const int x_in_frame = tx0 + px_l - 1;
+    const int y_in_frame = tr0 + py_l - 1;  // tensor row (top row first)
     const bool inside = x_in_frame < W && y_in_frame < H;
     const int xs = min(x_in_frame, W - 1), ys = min(y_in_frame, H - 1);  // safe addresses for idle lanes
     const size_t pix = (size_t)iib * frame + (size_t)ys * W + xs;
@@ -205,18 +231,8 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
     const bool q1_intended = (p.flags & DIRT_FLAG_Q1_INTENDED) != 0;
     const float width_f = (float)W, height_f = (float)H;
 
-    const int32_t face_here = inside ? s_vis[py_l + 1][px_l + 1] : -1;
-    Frag here;
-    int slot_here = -1;
-    if (face_here >= 0) {
-        here = frag_eval(recs, face_here, xs, ys, H);
-        slot_here = slot_insert(s_key, MAX_SLOTS, face_here);
-        if (slot_here < 0) slot_here = -2;
-    } else {  // clear values, csrc/rasterise_grad_egl.cpp:442-445
-        here.b[0] = here.b[1] = here.b[2] = -1.f;
-        here.w = INFINITY;
-        here.vid[0] = here.vid[1] = here.vid[2] = -1;
-    }
+    const int32_t face_here = inside ? s_vis[py_l][px_l] : -1;
+    const int slot_here = inside ? (int)s_slot[py_l][px_l] : -1;
     const Target t_here = make_target(slot_here, lane);
 
     for (int c_begin = 0; c_begin < C;) {
@@ -247,13 +263,13 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                         if (ox == 0 && oy == 0) { t[1][1] = 0.f; continue; }
                         float v;
                         if (real) {
-                            v = s_pix[ch][py_l + 1 - oy][px_l + 1 + ox];
+                            v = s_pix[ch][py_l - oy][px_l + ox];
                         } else {
                             // element (pixel + ch) of the flattened [B,H,W,1] slice; interior pixel, so
                             // the tap itself is unclamped
                             const int cc = x_in_frame + ox + ch;
                             if (cc <= W - 1) {
-                                v = s_pix[0][py_l + 1 - oy][px_l + 1 + ox + ch];
+                                v = s_pix[0][py_l - oy][px_l + ox + ch];
                             } else {
                                 size_t m = (size_t)iib * frame + (size_t)(y_in_frame - oy) * W + cc;
                                 if (m > total_pix - 1) m = total_pix - 1;
@@ -289,9 +305,8 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                 if (c < G) gb[c] = face_here >= 0 ? 0.f : gch[c];
         }
 
-        // ---- dilation, :155-194 ----
-        Frag cur = here;
-        int face_cur = face_here;
+        // ---- dilation, :155-194: which pixel's (barycentric, indices, clip_w) this pixel uses ----
+        int cy_l = py_l, cx_l = px_l;  // position (in the halo'd tile) of the fragment used
         bool dilated = false;
         if (interior) {
             float l1x, l1y;
@@ -303,17 +318,28 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
             }
             int off_x = l1x > l1y ? 1 : 0, off_y = l1x > l1y ? 0 : 1;
             if (((x_in_frame + y_in_frame) & 1) == 1) { off_x = -off_x; off_y = -off_y; }
-            for (int attempt = 0; attempt < 2 && !dilated; ++attempt) {
-                const int ox = attempt == 0 ? off_x : -off_x, oy = attempt == 0 ? off_y : -off_y;
-                // the reference offsets in GL buffer orientation (y up): tensor row = y_in_frame - oy
-                const int32_t face_off = s_vis[py_l + 1 - oy][px_l + 1 + ox];
-                if (face_off >= 0 && face_off != face_cur) {
-                    const Frag off = frag_eval(recs, face_off, x_in_frame + ox, y_in_frame - oy, H);
-                    const bool differs =
-                        off.vid[0] != cur.vid[0] || off.vid[1] != cur.vid[1] || off.vid[2] != cur.vid[2];
-                    if (differs && cur.w > off.w) {  // :165
-                        cur = off;
-                        face_cur = face_off;
+            const float w_here = s_frag[py_l][px_l].w;
+            const int s_h = slot_here;
+#pragma unroll
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                if (dilated) break;
+                // the reference offsets in GL buffer orientation (y up): tensor row = y - offset_y
+                const int ny = py_l - (attempt == 0 ? off_y : -off_y), nx = px_l + (attempt == 0 ? off_x : -off_x);
+                const int32_t face_off = s_vis[ny][nx];
+                if (face_off >= 0 && face_off != face_here) {
+                    // index triples: equal faces have equal triples; distinct faces are compared by vertex index
+                    const int s_o = s_slot[ny][nx];
+                    bool differs = true;
+                    if (face_here >= 0) {
+                        int a0, a1, a2, b0, b1, b2;
+                        if (s_h >= 0) { a0 = s_vid[s_h][0]; a1 = s_vid[s_h][1]; a2 = s_vid[s_h][2]; }
+                        else { a0 = recs[face_here].vid[0]; a1 = recs[face_here].vid[1]; a2 = recs[face_here].vid[2]; }
+                        if (s_o >= 0) { b0 = s_vid[s_o][0]; b1 = s_vid[s_o][1]; b2 = s_vid[s_o][2]; }
+                        else { b0 = recs[face_off].vid[0]; b1 = recs[face_off].vid[1]; b2 = recs[face_off].vid[2]; }
+                        differs = a0 != b0 || a1 != b1 || a2 != b2;
+                    }
+                    if (differs && w_here > s_frag[ny][nx].w) {  // :165
+                        cy_l = ny; cx_l = nx;
                         dilated = true;
                     }
                 }
@@ -331,13 +357,17 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
         }
 
         // ---- per-pixel contributions: colour (:135-142) and position (:196-232) ----
-        const bool covered = inside && face_cur >= 0;
-        int slot_cur = -1;
-        if (covered) {
-            slot_cur = (face_cur == face_here) ? slot_here : slot_insert(s_key, MAX_SLOTS, face_cur);
-            if (slot_cur == -1) slot_cur = -2;
-        }
+        const int32_t face_cur = inside ? s_vis[cy_l][cx_l] : -1;
+        const bool covered = face_cur >= 0;
+        const int slot_cur = covered ? (int)s_slot[cy_l][cx_l] : -1;
         const Target t_cur = make_target(slot_cur, lane);
+        const float4 fc4 = s_frag[cy_l][cx_l];
+        const float cb[3] = {fc4.x, fc4.y, fc4.z};
+        int vid_c[3] = {0, 0, 0};
+        if (covered) {
+            if (slot_cur >= 0) { vid_c[0] = s_vid[slot_cur][0]; vid_c[1] = s_vid[slot_cur][1]; vid_c[2] = s_vid[slot_cur][2]; }
+            else { vid_c[0] = recs[face_cur].vid[0]; vid_c[1] = recs[face_cur].vid[1]; vid_c[2] = recs[face_cur].vid[2]; }
+        }
         float dL_dx = 0.f, dL_dy = 0.f;
 #pragma unroll
         for (int channel = 0; channel < 3; ++channel) {
@@ -352,38 +382,40 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
         if (covered) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float2 vxy = *reinterpret_cast<const float2*>(vertices + (size_t)cur.vid[k] * 4);
-                float m = cur.b[k] * vxy.x;
+                const float2 vxy = *reinterpret_cast<const float2*>(vertices + (size_t)vid_c[k] * 4);
+                float m = cb[k] * vxy.x;
                 clip_x = clip_x + m;
-                m = cur.b[k] * vxy.y;
+                m = cb[k] * vxy.y;
                 clip_y = clip_y + m;
             }
         }
-        const float clip_w = cur.w;
+        const float clip_w = fc4.w;
         const float d_xview_by_xclip = (.5f * width_f) / clip_w;
         const float d_yview_by_yclip = (.5f * height_f) / clip_w;
         const float ww = clip_w * clip_w;
         const float d_xview_by_wclip = ((-.5f * width_f) * clip_x) / ww;
         const float d_yview_by_wclip = ((-.5f * height_f) * clip_y) / ww;
 
+        const float4 fh4 = s_frag[py_l][px_l];
+        const float hb[3] = {fh4.x, fh4.y, fh4.z};
         float val[NVAL];  // [0..8] position (k*3 + {x,y,w}), [9..17] colour (9 + k*3 + c)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float dLx_b = dL_dx * cur.b[k];
-            const float dLy_b = dL_dy * cur.b[k];
+            const float dLx_b = dL_dx * cb[k];
+            const float dLy_b = dL_dy * cb[k];
             const float gw1 = dLx_b * d_xview_by_wclip, gw2 = dLy_b * d_yview_by_wclip;
             val[k * 3 + 0] = covered ? dLx_b * d_xview_by_xclip : 0.f;
             val[k * 3 + 1] = covered ? dLy_b * d_yview_by_yclip : 0.f;
             val[k * 3 + 2] = covered ? gw1 + gw2 : 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) val[9 + k * 3 + c] = (face_here >= 0 && c < G) ? gch[c] * here.b[k] : 0.f;
+            for (int c = 0; c < 3; ++c) val[9 + k * 3 + c] = (face_here >= 0 && c < G) ? gch[c] * hb[k] : 0.f;
         }
 
         // faces that found no slot (table full): the reference's direct atomics
         if (slot_cur == -2) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                float* gv = grad_vertices + (size_t)cur.vid[k] * 4;
+                float* gv = grad_vertices + (size_t)vid_c[k] * 4;
                 atomicAdd(gv + 0, val[k * 3 + 0]);
                 atomicAdd(gv + 1, val[k * 3 + 1]);
                 atomicAdd(gv + 3, val[k * 3 + 2]);
@@ -394,7 +426,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    if (c < G) atomicAdd(&grad_vertex_colors[(size_t)here.vid[k] * C + c_begin + c], val[9 + k * 3 + c]);
+                    if (c < G) atomicAdd(&grad_vertex_colors[(size_t)recs[face_here].vid[k] * C + c_begin + c], val[9 + k * 3 + c]);
         }
 
         // ---- quad pre-reduction and the tile-wide magnitude of what will be added ----
@@ -422,7 +454,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
         } else if (t_cur.active) {  // inf / NaN somewhere in the tile: float atomics keep IEEE semantics
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                float* gv = grad_vertices + (size_t)cur.vid[k] * 4;
+                float* gv = grad_vertices + (size_t)vid_c[k] * 4;
                 atomicAdd(gv + 0, val[k * 3 + 0]);
                 atomicAdd(gv + 1, val[k * 3 + 1]);
                 atomicAdd(gv + 3, val[k * 3 + 2]);
@@ -436,15 +468,14 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    if (c < G) atomicAdd(&grad_vertex_colors[(size_t)here.vid[k] * C + c_begin + c], val[9 + k * 3 + c]);
+                    if (c < G) atomicAdd(&grad_vertex_colors[(size_t)s_vid[slot_here][k] * C + c_begin + c], val[9 + k * 3 + c]);
         }
         __syncthreads();
 
         // ---- flush: one global atomic per (face, vertex, component) for the whole tile ----
         for (int e = tid; e < MAX_SLOTS * NVAL; e += GTHREADS) {
             const int slot = e / NVAL, v = e - slot * NVAL;
-            const int32_t face = s_key[slot];
-            if (face < 0) continue;
+            if (s_key[slot] < 0) continue;
             unsigned long long* a = &s_acc[e * COPIES];
             long long sum = 0;
 #pragma unroll
@@ -453,10 +484,10 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
             const float f = (float)((double)sum * (double)(v < 9 ? fp.from_fix : fc.from_fix));
             if (v < 9) {
                 const int k = v / 3, comp = v - k * 3;
-                atomicAdd(&grad_vertices[(size_t)recs[face].vid[k] * 4 + (comp == 2 ? 3 : comp)], f);
+                atomicAdd(&grad_vertices[(size_t)s_vid[slot][k] * 4 + (comp == 2 ? 3 : comp)], f);
             } else {
                 const int k = (v - 9) / 3, c = (v - 9) - k * 3;
-                if (c < G) atomicAdd(&grad_vertex_colors[(size_t)recs[face].vid[k] * C + c_begin + c], f);
+                if (c < G) atomicAdd(&grad_vertex_colors[(size_t)s_vid[slot][k] * C + c_begin + c], f);
             }
         }
         __syncthreads();
