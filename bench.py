@@ -45,11 +45,10 @@ def kernel_algorithmic_bytes(P, V, F, C):
     of its own (its output is an intermediate); grad reads pixels, grad_pixels, vertices and writes
     the three gradients."""
     return {
-        'setup_kernel': 12 * F + 16 * V,
+        'geometry (setup+fill)': 12 * F + 16 * V,
         'raster_kernel<shade>': 8 * P * C + 4 * V * C,
         'raster_kernel<visibility>': 0,
         'grad_kernel': 12 * P * C + 16 * V + 16 * V + 4 * V * C,
-        'memset': 0,
     }
 
 
@@ -93,8 +92,10 @@ def main():
     bg, v, vc, f, g = (t(batch[k]) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels'))
 
     def step(flags=0):
-        px = ops._op_rasterise(bg, v, vc, f, H, W, C, flags=flags)
-        return ops._op_rasterise_grad(v, f, px, g, H, W, C, flags=flags)
+        # exactly what torch.autograd does through dirt_amd.rasterise_batch: the forward leaves its
+        # set-up records + visibility in a private state buffer, the backward consumes it
+        px, state = ops._op_rasterise(bg, v, vc, f, H, W, C, flags=flags, keep_state=True)
+        return ops._op_rasterise_grad(v, f, px, g, H, W, C, flags=flags, state=state)
 
     def barrier():
         if distributed:

@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, 'libdirt_hip.so')
 ABI_VERSION = 1
 
 FLAG_Q1_INTENDED = 1
+FLAG_KEEP_STATE = 2
+FLAG_REUSE_STATE = 4
 FLAG_PROFILE = 0x100
 
 E_INVALID_ARGUMENT = -1

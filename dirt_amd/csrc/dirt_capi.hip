@@ -222,6 +222,7 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
     }
     dirt::RasterParams p = raster_params(c, g, C);
     p.background = background; p.vertex_colors = vertex_colors; p.pixels = pixels;
+    if (flags & DIRT_FLAG_KEEP_STATE) p.vis = c.vis;  // the records already live in the workspace
     {
         Scope sc(prof, SLOT_RASTER_FWD, stream);
         HIP_TRY(who, dirt::launch_raster(p, B, false, stream));
@@ -282,21 +283,28 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const Carved c = carved(workspace, w);
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
-    dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W);
     // the cudaMemsetAsync x4 of csrc/rasterise_grad_egl.cu:244-250: grad_vertices / grad_vertex_colors
-    // are cleared by the same launch that clears the bin counters; grad_background and debug_thingy
-    // are fully written by the gradient kernel instead
-    g.zero_b = grad_vertices;      g.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
-    g.zero_c = grad_vertex_colors; g.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
-    {
+    // are cleared by one launch; grad_background and debug_thingy are fully written by the gradient
+    // kernel instead
+    if (flags & DIRT_FLAG_REUSE_STATE) {
+        // records + visibility were left in this workspace by the forward pass
         Scope sc(prof, SLOT_GEOMETRY, stream);
-        HIP_TRY(who, dirt::launch_geometry(g, stream));
-    }
-    dirt::RasterParams rp = raster_params(c, g, C);
-    rp.vis = c.vis;
-    {
-        Scope sc(prof, SLOT_RASTER_VIS, stream);
-        HIP_TRY(who, dirt::launch_raster(rp, B, true, stream));
+        HIP_TRY(who, dirt::launch_zero(grad_vertices, sizeof(float) * (size_t)B * V * 4, grad_vertex_colors,
+                                       sizeof(float) * (size_t)B * V * C, stream));
+    } else {
+        dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W);
+        g.zero_b = grad_vertices;      g.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
+        g.zero_c = grad_vertex_colors; g.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
+        {
+            Scope sc(prof, SLOT_GEOMETRY, stream);
+            HIP_TRY(who, dirt::launch_geometry(g, stream));
+        }
+        dirt::RasterParams rp = raster_params(c, g, C);
+        rp.vis = c.vis;
+        {
+            Scope sc(prof, SLOT_RASTER_VIS, stream);
+            HIP_TRY(who, dirt::launch_raster(rp, B, true, stream));
+        }
     }
     int32_t* vis = c.vis;
     auto* recs = c.recs;

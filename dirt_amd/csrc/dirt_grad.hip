@@ -32,6 +32,18 @@
 
 namespace dirt {
 
+#ifdef DIRT_TRACE
+__device__ long long* g_trace_grad = nullptr;
+extern "C" void dirt_debug_set_trace_grad(void* p)
+{
+    long long* q = reinterpret_cast<long long*>(p);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_grad), &q, sizeof(q));
+}
+#define GMARK() do { if (tr_n < 16) tr_t[tr_n++] = clock64(); } while (0)
+#else
+#define GMARK() do {} while (0)
+#endif
+
 constexpr int GW = 32, GH = 16;        // tile = 32 x 16 pixels, one pixel per lane
 constexpr int GTHREADS = 512;          // 8 waves = 4 x 2 blocks of 8 x 8 pixels
 constexpr int PW = GW + 4;             // staged `pixels` columns: x0-1 .. x0+34 (halo + 2 for the Q1 alias taps)
@@ -166,6 +178,10 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
     __shared__ int32_t s_vid[MAX_SLOTS][3];                          // slot -> the face's vertex indices
     __shared__ uint32_t s_max[2];                                    // largest |position| / |colour| contribution (float bits)
 
+#ifdef DIRT_TRACE
+    long long tr_t[16]; int tr_n = 0;
+#endif
+    GMARK();  // 0 start
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -189,6 +205,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
     for (int i = tid; i < MAX_SLOTS * NVAL * COPIES; i += GTHREADS) s_acc[i] = 0ull;
     if (tid < 2) s_max[tid] = 0u;
     __syncthreads();
+    GMARK();  // 1 init
 
     // ---- phase A: the visibility "surfaces" of the tile + 1-pixel halo, what the backward fragment
     //      shader writes (csrc/shaders.cpp:64-77) over the clear values of
@@ -210,7 +227,9 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
         s_frag[vy][vx] = fr;
         s_slot[vy][vx] = (int16_t)slot;
     }
+    GMARK();  // 2 phase A body
     __syncthreads();
+    GMARK();  // 3 phase A barrier
     if (tid < MAX_SLOTS) {
         const int32_t face = s_key[tid];
         if (face >= 0) {
@@ -246,7 +265,9 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
             const int cy = min(max(tr0 + yy - 1, 0), H - 1), cx = min(max(tx0 + xx - 1, 0), W - 1);
             s_pix[ch][yy][xx] = pixels[((size_t)cy * W + cx) * C + c_begin + ch];
         }
+        GMARK();  // stage body
         __syncthreads();
+        GMARK();  // stage barrier
 
         // ---- Scharr, :126-127 (negative-offset minus positive-offset; offset_y is up) ----
         float sx[3], sy[3];
@@ -429,6 +450,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                     if (c < G) atomicAdd(&grad_vertex_colors[(size_t)recs[face_here].vid[k] * C + c_begin + c], val[9 + k * 3 + c]);
         }
 
+        GMARK();  // per-pixel math done
         // ---- quad pre-reduction and the tile-wide magnitude of what will be added ----
         uint32_t mp = 0u, mc = 0u;
 #pragma unroll
@@ -445,6 +467,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
             if (mc) atomicMax(&s_max[1], mc);
         }
         __syncthreads();
+        GMARK();  // max barrier
 
         // ---- fixed-point accumulation (integer LDS atomics: exact, order independent) ----
         const FixScale fp = fix_scale(s_max[0]), fc = fix_scale(s_max[1]);
@@ -470,6 +493,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                 for (int c = 0; c < 3; ++c)
                     if (c < G) atomicAdd(&grad_vertex_colors[(size_t)s_vid[slot_here][k] * C + c_begin + c], val[9 + k * 3 + c]);
         }
+        GMARK();  // accumulated
         __syncthreads();
 
         // ---- flush: one global atomic per (face, vertex, component) for the whole tile ----
@@ -490,10 +514,17 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                 if (c < G) atomicAdd(&grad_vertex_colors[(size_t)s_vid[slot][k] * C + c_begin + c], f);
             }
         }
+        GMARK();  // flushed
         __syncthreads();
         if (tid < 2) s_max[tid] = 0u;  // ordered before the next group's atomicMax by its staging barrier
         c_begin += G;
     }
+#ifdef DIRT_TRACE
+    if (lane == 0 && g_trace_grad) {
+        long long* o = g_trace_grad + ((size_t)blockIdx.x * 8 + wave) * 16;
+        for (int i = 0; i < 16; ++i) o[i] = i < tr_n ? tr_t[i] : 0;
+    }
+#endif
 }
 
 hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)

@@ -55,7 +55,7 @@ struct RasterParams {
     const float* background;     // [B,H,W,C]
     const float* vertex_colors;  // [B,V,C]
     float* pixels;               // [B,H,W,C]
-    int32_t* vis;                // [B,H,W] visibility export (MODE 1)
+    int32_t* vis;                // [B,H,W] visibility export (MODE 1; optional in MODE 0)
     int V, F, H, W, C;
     BinGrid grid;
     int tiles_x, tiles_y;        // filled by launch_raster
@@ -79,6 +79,7 @@ struct GradParams {
 
 BinGrid make_bin_grid(int H, int W);
 void chunking(int F, int& nchunk, int& chunk_faces);
+hipError_t launch_zero(void* b, size_t b_bytes, void* c, size_t c_bytes, hipStream_t stream);
 hipError_t launch_geometry(const GeomParams& g, hipStream_t stream);
 hipError_t launch_raster(const RasterParams& p, int B, bool visibility_only, hipStream_t stream);
 hipError_t launch_grad(const GradParams& p, hipStream_t stream);

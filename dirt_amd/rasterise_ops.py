@@ -96,8 +96,12 @@ def _require_gpu(*tensors):
     return dev
 
 
-def _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels, flags=0):
-    """`_rasterise_module.rasterise` (dirt/rasterise_ops.py:81-85): the raw forward op, no autograd."""
+def _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels, flags=0, keep_state=False):
+    """`_rasterise_module.rasterise` (dirt/rasterise_ops.py:81-85): the raw forward op, no autograd.
+
+    With keep_state=True returns (pixels, state): `state` is a private workspace holding the set-up
+    records and the visibility buffer, to be handed to `_op_rasterise_grad(..., state=state)` so the
+    backward pass does not render again (DIRT_FLAG_KEEP_STATE / DIRT_FLAG_REUSE_STATE)."""
     lib = _lib.load()
     _check_forward_shapes(background, vertices, vertex_colors, faces, height, width, channels)
     dev = _require_gpu(background, vertices, vertex_colors, faces)
@@ -108,14 +112,19 @@ def _op_rasterise(background, vertices, vertex_colors, faces, height, width, cha
         nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, channels)
         if nbytes == 0:
             raise ValueError(_lib.last_error())
-        ws = _workspace(dev, nbytes)
+        if keep_state:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            flags |= _lib.FLAG_KEEP_STATE
+        else:
+            ws = _workspace(dev, nbytes)
         _lib.check(lib.dirt_rasterise_forward(
             background.data_ptr(), vertices.data_ptr(), vertex_colors.data_ptr(), faces.data_ptr(), pixels.data_ptr(),
             B, V, F, height, width, channels, ws.data_ptr(), ws.numel(), flags, torch.cuda.current_stream(dev).cuda_stream))
-    return pixels
+    return (pixels, ws) if keep_state else pixels
 
 
-def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, channels, flags=0, want_debug=False):
+def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, channels, flags=0, want_debug=False,
+                       state=None):
     """`_rasterise_module.rasterise_grad` (dirt/rasterise_ops.py:113-118): returns
     (grad_background, grad_vertices, grad_vertex_colors, debug_thingy or None)."""
     lib = _lib.load()
@@ -133,7 +142,11 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
         nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, channels)
         if nbytes == 0:
             raise ValueError(_lib.last_error())
-        ws = _workspace(dev, nbytes)
+        if state is not None:
+            ws = state
+            flags |= _lib.FLAG_REUSE_STATE
+        else:
+            ws = _workspace(dev, nbytes)
         _lib.check(lib.dirt_rasterise_backward(
             vertices.data_ptr(), faces.data_ptr(), pixels.data_ptr(), grad_pixels.data_ptr(),
             grad_background.data_ptr(), grad_vertices.data_ptr(), grad_vertex_colors.data_ptr(),
@@ -164,8 +177,13 @@ class _Rasterise(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, background, vertices, vertex_colors, faces, height, width, channels):
-        pixels = _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels)
+        needs_grad = any(ctx.needs_input_grad[:3])
+        if needs_grad:
+            pixels, state = _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels, keep_state=True)
+        else:
+            pixels, state = _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels), None
         ctx.save_for_backward(vertices, faces, pixels)  # op.inputs[1], op.inputs[3], op.outputs[0]
+        ctx.state = state  # set-up records + visibility of this very call (never shared with other calls)
         ctx.hwc = (height, width, channels)
         return pixels
 
@@ -174,7 +192,7 @@ class _Rasterise(torch.autograd.Function):
         vertices, faces, pixels = ctx.saved_tensors
         height, width, channels = ctx.hwc
         grad_background, grad_vertices, grad_vertex_colors, _ = _op_rasterise_grad(
-            vertices, faces, pixels, grad_pixels.to(torch.float32), height, width, channels)
+            vertices, faces, pixels, grad_pixels.to(torch.float32), height, width, channels, state=ctx.state)
         return grad_background, grad_vertices, grad_vertex_colors, None, None, None, None  # None wrt faces
 
 

@@ -46,6 +46,17 @@ extern "C" {
                                     channel reads (csrc/rasterise_grad_egl.cu:119-123,185; SURVEY.md
                                     App. A.3 quirk Q1).  Default (0) reproduces the reference. */
 
+#define DIRT_FLAG_KEEP_STATE 2u  /* forward: also leave, in `workspace`, the state the backward pass needs
+                                    (per-face set-up records and the per-pixel front-most face). */
+#define DIRT_FLAG_REUSE_STATE 4u /* backward: `workspace` is the very buffer a forward call with
+                                    DIRT_FLAG_KEEP_STATE filled for the same vertices, faces and sizes, and
+                                    nothing has written to it since: skip triangle set-up and the visibility
+                                    render.  The reference re-renders in RasteriseGrad and notes the
+                                    alternative itself (csrc/rasterise_grad_egl.cpp:446-447: "It may or may
+                                    not more efficient to render these in the forward pass and return them
+                                    in separate outputs").  The state is caller-owned memory; the library
+                                    stays stateless.  Results are identical with or without the flag. */
+
 #define DIRT_FLAG_PROFILE 0x100u /* record a HIP-event pair around every kernel this call launches (on the
                                     call's stream); read the totals with dirt_profile_read.  Replaces the
                                     reference's compile-time TIME_SECTIONS wall-clock prints

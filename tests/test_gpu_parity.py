@@ -145,3 +145,21 @@ def test_golden_fixtures_on_gpu(gpu):
         assert np.array_equal(gb.cpu().numpy(), z['grad_background']), name
         _assert_grad_close(gv.cpu().numpy(), z['grad_vertices'], name + ' gv')
         _assert_grad_close(gvc.cpu().numpy(), z['grad_vertex_colors'], name + ' gvc')
+
+
+def test_state_reuse_is_identical(gpu, oracle):
+    """DIRT_FLAG_KEEP_STATE / DIRT_FLAG_REUSE_STATE: the backward pass fed with the forward's records +
+    visibility gives the same result as the stateless one that renders again."""
+    s = _batched(scenes.rand_scene(600, 100, 140, 4, 41, 0.02, 0.2))
+    args = [_t(s[k], gpu) for k in ('background', 'vertices', 'vertex_colors', 'faces')]
+    px, state = ops._op_rasterise(*args, 100, 140, 4, keep_state=True)
+    px2 = ops._op_rasterise(*args, 100, 140, 4)
+    assert torch.equal(px, px2)
+    g = _t(s['grad_pixels'], gpu)
+    a = ops._op_rasterise_grad(args[1], args[3], px, g, 100, 140, 4, state=state)
+    b = ops._op_rasterise_grad(args[1], args[3], px, g, 100, 140, 4)
+    assert torch.equal(a[0], b[0])
+    ow = oracle.backward(s['vertices'], s['faces'], px.cpu().numpy(), s['grad_pixels'])
+    for got in (a, b):
+        _assert_grad_close(got[1].cpu().numpy(), ow['grad_vertices'], 'gv')
+        _assert_grad_close(got[2].cpu().numpy(), ow['grad_vertex_colors'], 'gvc')
