@@ -19,12 +19,15 @@
 //   * the sums are accumulated in FIXED POINT with 64-bit integer LDS atomics.  Measured on MI355X
 //     (tools/lds_atomic_bench.hip): ds_add_f32 is serialised per active lane (~3 clk/lane for the
 //     whole CU, whatever the addresses), ds_add_u64 runs at full rate for distinct addresses and
-//     2 clk/lane for equal ones.  The power-of-two scale comes from the tile-wide largest
-//     contribution (DPP wave max + one LDS atomicMax per wave), so a contribution keeps 27 bits
-//     relative to the largest one and the tile sum is exact and order independent;
-//   * per group the replicas are summed and ONE global float atomic per (face, vertex, component)
-//     is issued for the whole tile.  Faces that do not fit the slot table, and tiles that see an
-//     inf / NaN contribution, fall back to the reference's direct float atomics.
+//     2 clk/lane for equal ones.  The power-of-two scale comes from tile-wide bounds that are known
+//     before any contribution is computed (max |grad_pixels|, max |pixels|, max 1/clip_w over the
+//     tile: three LDS atomicMax per wave), so no barrier separates computing a contribution from
+//     adding it; contributions keep >= 2^-20 relative precision against the tile's largest one in
+//     practice and the tile sum is exact and order independent;
+//   * per pass (<= 4 channels = the channel groups that fit) the replicas are summed and ONE global
+//     float atomic per (face, vertex, component) is issued for the whole tile.  Faces that do not
+//     fit the slot table, and tiles that see an inf / NaN, fall back to the reference's direct
+//     float atomics.
 // Variable names in the per-pixel arithmetic follow the CUDA source.
 #include "dirt_device.h"
 #include "dirt_launch.h"
@@ -51,8 +54,9 @@ constexpr int PH = GH + 2;             // staged rows: y0-1 .. y0+16
 constexpr int VW = GW + 2;             // visibility tile with a 1-pixel halo
 constexpr int COPIES = 2;              // accumulator replicas per (slot, value)
 constexpr int MAX_SLOTS = 64;          // slot table capacity (LDS)
-constexpr int NVAL = 18;               // 9 position values (3 vertices x {x,y,w}) + 3 vertices x 3 group channels
-constexpr int FIX_BITS = 27;           // fixed-point contributions: |q| < 2^(FIX_BITS+1)
+constexpr int PC = 4;                  // channels per pass: whole channel groups that fit in 4 channels
+constexpr int NVAL = 9 + 3 * PC;       // 9 position values (3 vertices x {x,y,w}) + 3 vertices x PC colour values
+constexpr int FIX_BITS = 29;           // fixed-point contributions: |q| < 2^FIX_BITS given the tile bound
 
 struct Frag {
     float b[3];
@@ -128,7 +132,7 @@ __device__ __forceinline__ Target make_target(int slot, int lane)
     t.slot = slot;
     const int s0 = __builtin_amdgcn_mov_dpp(slot, 0x00, 0xF, 0xF, true);  // quad_perm [0,0,0,0]
     const unsigned long long m = __ballot(slot == s0);
-    t.uniform = ((m >> (lane & ~3)) & 0xFull) == 0xFull;
+    t.uniform = ((m >> (lane & ~3)) & 0xFull) == 0xFull && slot != -2;  // -2 lanes may belong to different faces
     t.active = slot >= 0 && (t.uniform ? (lane & 3) == 0 : true);
     t.copy = (lane >> 2) & (COPIES - 1);
     return t;
@@ -142,41 +146,50 @@ __device__ __forceinline__ float quad_reduce(const Target& t, float v)
     return t.uniform ? q : v;
 }
 
-// Power-of-two scale for fixed-point accumulation from the largest |contribution| (float bits).
+// Power-of-two scale for fixed-point accumulation: contributions are bounded by `bound` (> 0,
+// finite), so |v * to_fix| < 2^FIX_BITS.
 struct FixScale {
-    float to_fix;    // 2^(FIX_BITS - E)
+    float to_fix;    // 2^(FIX_BITS - 1 - E), E = exponent of the bound
     float from_fix;  // its inverse
-    bool finite;     // false: inf / NaN present -> the group falls back to direct float atomics
+    bool finite;     // false: inf / NaN in the tile -> direct float atomics keep IEEE semantics
 };
 
-__device__ __forceinline__ FixScale fix_scale(uint32_t max_bits)
+__device__ __forceinline__ FixScale fix_scale(float bound)
 {
-    uint32_t e = max_bits >> 23;  // biased exponent of the largest magnitude (sign bit is clear)
+    const uint32_t bits = __float_as_uint(bound) & 0x7FFFFFFFu;
+    uint32_t e = bits >> 23;  // biased exponent: |v| <= bound < 2^(e - 126)
     FixScale f;
     f.finite = e < 255u;
-    e = min(max(e, 28u + 0u), 254u);
-    f.to_fix = __uint_as_float((uint32_t)(127 + FIX_BITS + 127 - (int)e) << 23);
-    f.from_fix = __uint_as_float((uint32_t)((int)e - FIX_BITS) << 23);
+    e = min(max(e, 32u), 220u);
+    f.to_fix = __uint_as_float((uint32_t)(127 + FIX_BITS - 1 + 126 - (int)e) << 23);
+    f.from_fix = __uint_as_float((uint32_t)(127 - (FIX_BITS - 1) - 126 + (int)e) << 23);
     return f;
 }
 
-__device__ __forceinline__ void fix_add(unsigned long long* acc, const Target& t, int idx, float v, float to_fix)
+// N fixed-point adds (values idx0 .. idx0+N-1 of the lane's slot) under one exec mask.
+template <int N>
+__device__ __forceinline__ void fix_add(unsigned long long* acc, const Target& t, int idx0, const float* v, float to_fix)
 {
-    const int q = (int)rintf(v * to_fix);
-    if (t.active && q != 0)
-        atomicAdd(&acc[(t.slot * NVAL + idx) * COPIES + t.copy], (unsigned long long)(long long)q);
+    if (t.active) {
+        unsigned long long* a = &acc[(t.slot * NVAL + idx0) * COPIES + t.copy];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int q = (int)rintf(v[i] * to_fix);
+            atomicAdd(a + i * COPIES, (unsigned long long)(long long)q);
+        }
+    }
 }
 
 __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
 {
-    __shared__ float s_pix[3][PH][PW];                               // the current group's channels of `pixels`, edge clamped
+    __shared__ float s_pix[PC][PH][PW];                              // the pass's channels of `pixels`, edge clamped
     __shared__ unsigned long long s_acc[MAX_SLOTS * NVAL * COPIES];  // fixed-point partial sums
     __shared__ float4 s_frag[PH][VW];                                // (b0,b1,b2,clip_w) of every pixel of the halo'd tile
     __shared__ int32_t s_vis[PH][VW];                                // its front-most face
     __shared__ int16_t s_slot[PH][VW];                               // and that face's slot (-1 none, -2 table full)
     __shared__ int32_t s_key[MAX_SLOTS];                             // slot -> face
     __shared__ int32_t s_vid[MAX_SLOTS][3];                          // slot -> the face's vertex indices
-    __shared__ uint32_t s_max[2];                                    // largest |position| / |colour| contribution (float bits)
+    __shared__ uint32_t s_bound[3];                                  // tile maxima (float bits): |grad_pixels|, |pixels|, 1/clip_w
 
 #ifdef DIRT_TRACE
     long long tr_t[16]; int tr_n = 0;
@@ -195,48 +208,9 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
 
     const FaceRec* __restrict__ recs = p.recs + (size_t)iib * p.F;
     const int32_t* __restrict__ vis = p.vis + (size_t)iib * frame;
-    const float* __restrict__ vertices = p.vertices + (size_t)iib * p.V * 4;
     const float* __restrict__ pixels = p.pixels + (size_t)iib * frame * C;
     float* __restrict__ grad_vertices = p.grad_vertices + (size_t)iib * p.V * 4;
     float* __restrict__ grad_vertex_colors = p.grad_vertex_colors + (size_t)iib * p.V * C;
-
-    // ---- init ----
-    for (int i = tid; i < MAX_SLOTS; i += GTHREADS) s_key[i] = -1;
-    for (int i = tid; i < MAX_SLOTS * NVAL * COPIES; i += GTHREADS) s_acc[i] = 0ull;
-    if (tid < 2) s_max[tid] = 0u;
-    __syncthreads();
-    GMARK();  // 1 init
-
-    // ---- phase A: the visibility "surfaces" of the tile + 1-pixel halo, what the backward fragment
-    //      shader writes (csrc/shaders.cpp:64-77) over the clear values of
-    //      csrc/rasterise_grad_egl.cpp:442-445.  Halo positions outside the frame are clamped; they
-    //      are only ever consulted for interior pixels, whose neighbours are inside the frame. ----
-    for (int i = tid; i < PH * VW; i += GTHREADS) {
-        const int vy = i / VW, vx = i - vy * VW;
-        const int rr = min(max(tr0 + vy - 1, 0), H - 1), xx = min(max(tx0 + vx - 1, 0), W - 1);
-        const int32_t face = vis[(size_t)rr * W + xx];
-        float4 fr = make_float4(-1.f, -1.f, -1.f, INFINITY);
-        int slot = -1;
-        if (face >= 0) {
-            const Frag f = frag_eval(recs, face, xx, rr, H);
-            fr = make_float4(f.b[0], f.b[1], f.b[2], f.w);
-            slot = slot_insert(s_key, MAX_SLOTS, face);
-            if (slot < 0) slot = -2;
-        }
-        s_vis[vy][vx] = face;
-        s_frag[vy][vx] = fr;
-        s_slot[vy][vx] = (int16_t)slot;
-    }
-    GMARK();  // 2 phase A body
-    __syncthreads();
-    GMARK();  // 3 phase A barrier
-    if (tid < MAX_SLOTS) {
-        const int32_t face = s_key[tid];
-        if (face >= 0) {
-            s_vid[tid][0] = recs[face].vid[0]; s_vid[tid][1] = recs[face].vid[1]; s_vid[tid][2] = recs[face].vid[2];
-        }
-    }
-    // (the first group's staging barrier publishes s_vid)
 
     // ---- this lane's pixel ----
     const int px_l = (wave & 3) * 8 + (lane & 7) + 1, py_l = (wave >> 2) * 8 + (lane >> 3) + 1;  // in the halo'd tile
@@ -250,253 +224,290 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
     const bool q1_intended = (p.flags & DIRT_FLAG_Q1_INTENDED) != 0;
     const float width_f = (float)W, height_f = (float)H;
 
-    const int32_t face_here = inside ? s_vis[py_l][px_l] : -1;
-    const int slot_here = inside ? (int)s_slot[py_l][px_l] : -1;
-    const Target t_here = make_target(slot_here, lane);
+    // ---- init ----
+    for (int i = tid; i < MAX_SLOTS; i += GTHREADS) s_key[i] = -1;
+    for (int i = tid; i < MAX_SLOTS * NVAL * COPIES; i += GTHREADS) s_acc[i] = 0ull;
+    if (tid < 3) s_bound[tid] = 0u;
+    __syncthreads();
+    GMARK();  // 1 init
 
-    for (int c_begin = 0; c_begin < C;) {
-        const int G = (c_begin + 3 <= C) ? 3 : 1;     // dirt/rasterise_ops.py:148-152
-        const bool alias = (G == 1) && !q1_intended;  // quirk Q1: "channels" 1,2 of a 1-channel tensor
+    // ---- phase A: the visibility "surfaces" of the tile + 1-pixel halo, what the backward fragment
+    //      shader writes (csrc/shaders.cpp:64-77) over the clear values of
+    //      csrc/rasterise_grad_egl.cpp:442-445.  Halo positions outside the frame are clamped; they
+    //      are only ever consulted for interior pixels, whose neighbours are inside the frame. ----
+    float rcpw_max = 0.f;
+    for (int i = tid; i < PH * VW; i += GTHREADS) {
+        const int vy = i / VW, vx = i - vy * VW;
+        const int rr = min(max(tr0 + vy - 1, 0), H - 1), xx = min(max(tx0 + vx - 1, 0), W - 1);
+        const int32_t face = vis[(size_t)rr * W + xx];
+        float4 fr = make_float4(-1.f, -1.f, -1.f, INFINITY);
+        int slot = -1;
+        if (face >= 0) {
+            const Frag f = frag_eval(recs, face, xx, rr, H);
+            fr = make_float4(f.b[0], f.b[1], f.b[2], f.w);
+            rcpw_max = fmaxf(rcpw_max, fabsf(1.0f / f.w));
+            slot = slot_insert(s_key, MAX_SLOTS, face);
+            if (slot < 0) slot = -2;
+        }
+        s_vis[vy][vx] = face;
+        s_frag[vy][vx] = fr;
+        s_slot[vy][vx] = (int16_t)slot;
+    }
+    {
+        const uint32_t m = wave_max_u32(__float_as_uint(rcpw_max));
+        if (lane == 0 && m) atomicMax(&s_bound[2], m);
+    }
+    GMARK();  // 2 phase A body
 
-        // ---- stage the group's channels of the pixels tile (+halo), edge clamped: at(), :113-124 ----
-        for (int i = tid; i < G * PH * PW; i += GTHREADS) {
+    for (int c0 = 0; c0 < C;) {
+        // ---- the pass: whole channel groups (dirt/rasterise_ops.py:148-152) starting at c0 that fit in PC channels ----
+        int nch = 0;
+        for (int c = c0; c < C && nch < PC;) {
+            const int G = (c + 3 <= C) ? 3 : 1;
+            if (nch + G > PC) break;
+            nch += G; c += G;
+        }
+        // ---- stage the pass's channels of the pixels tile (+halo), edge clamped: at(), :113-124 ----
+        float pmax = 0.f, gmax = 0.f;
+        for (int i = tid; i < nch * PH * PW; i += GTHREADS) {
             const int ch = i / (PH * PW), rem = i - ch * (PH * PW);
             const int yy = rem / PW, xx = rem - yy * PW;
             const int cy = min(max(tr0 + yy - 1, 0), H - 1), cx = min(max(tx0 + xx - 1, 0), W - 1);
-            s_pix[ch][yy][xx] = pixels[((size_t)cy * W + cx) * C + c_begin + ch];
+            const float v = pixels[((size_t)cy * W + cx) * C + c0 + ch];
+            s_pix[ch][yy][xx] = v;
+            pmax = fmaxf(pmax, fabsf(v));
         }
-        GMARK();  // stage body
+        float gch[PC];
+#pragma unroll
+        for (int c = 0; c < PC; ++c) {
+            gch[c] = (c < nch) ? g_here[c0 + c] : 0.f;
+            gmax = fmaxf(gmax, fabsf(gch[c]));
+        }
+        // NaNs do not survive fmaxf: fold them in explicitly so the inf/NaN fallback sees them
+        if (!(pmax == pmax)) pmax = INFINITY;
+        {
+            bool gnan = false;
+#pragma unroll
+            for (int c = 0; c < PC; ++c) gnan |= !(gch[c] == gch[c]);
+            if (gnan) gmax = INFINITY;
+            const uint32_t mg = wave_max_u32(__float_as_uint(gmax)), mp = wave_max_u32(__float_as_uint(pmax));
+            if (lane == 0) {
+                if (mg) atomicMax(&s_bound[0], mg);
+                if (mp) atomicMax(&s_bound[1], mp);
+            }
+        }
         __syncthreads();
-        GMARK();  // stage barrier
-
-        // ---- Scharr, :126-127 (negative-offset minus positive-offset; offset_y is up) ----
-        float sx[3], sy[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            float t[3][3];
-            const bool real = ch < G;
-            const bool aliased = !real && alias && interior;
-            if (real || aliased) {
-#pragma unroll
-                for (int oy = -1; oy <= 1; ++oy)
-#pragma unroll
-                    for (int ox = -1; ox <= 1; ++ox) {
-                        if (ox == 0 && oy == 0) { t[1][1] = 0.f; continue; }
-                        float v;
-                        if (real) {
-                            v = s_pix[ch][py_l - oy][px_l + ox];
-                        } else {
-                            // element (pixel + ch) of the flattened [B,H,W,1] slice; interior pixel, so
-                            // the tap itself is unclamped
-                            const int cc = x_in_frame + ox + ch;
-                            if (cc <= W - 1) {
-                                v = s_pix[0][py_l - oy][px_l + ox + ch];
-                            } else {
-                                size_t m = (size_t)iib * frame + (size_t)(y_in_frame - oy) * W + cc;
-                                if (m > total_pix - 1) m = total_pix - 1;
-                                v = p.pixels[m * C + c_begin];
-                            }
-                        }
-                        t[oy + 1][ox + 1] = v;
-                    }
-#define AT(ox, oy) t[(oy) + 1][(ox) + 1]
-                float d1 = ((AT(-1, -1) + AT(-1, +1)) - AT(+1, -1)) - AT(+1, +1);
-                float d2 = AT(-1, 0) - AT(+1, 0);
-                float m1 = d1 * (3.f / 32.f), m2 = d2 * (10.f / 32.f);
-                sx[ch] = m1 + m2;
-                d1 = ((AT(-1, -1) + AT(+1, -1)) - AT(-1, +1)) - AT(+1, +1);
-                d2 = AT(0, -1) - AT(0, +1);
-                m1 = d1 * (3.f / 32.f); m2 = d2 * (10.f / 32.f);
-                sy[ch] = m1 + m2;
-#undef AT
-            } else {
-                sx[ch] = 0.f; sy[ch] = 0.f;
+        GMARK();  // 3 staged
+        if (tid < MAX_SLOTS && c0 == 0) {
+            const int32_t face = s_key[tid];
+            if (face >= 0) {
+                s_vid[tid][0] = recs[face].vid[0]; s_vid[tid][1] = recs[face].vid[1]; s_vid[tid][2] = recs[face].vid[2];
             }
         }
+        if (c0 == 0) __syncthreads();
+        GMARK();  // 4 vids
 
-        float gch[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gch[c] = (c < G) ? g_here[c_begin + c] : 0.f;
+        // ---- fixed-point scales from tile-wide bounds (no data-dependent barrier needed):
+        //      |colour contribution|   = |g * b|, b <= 1                      <= gmax
+        //      |position contribution| <= |dL_dx| * b * max(W,H) * |1/w|,  |dL_dx| <= 3 * gmax * |Scharr| <= 3 * gmax * pmax
+        //      both times 4 for the quad pre-reduction and 2 for rounding slack ----
+        const float gb = __uint_as_float(s_bound[0]), pb = __uint_as_float(s_bound[1]), wb = __uint_as_float(s_bound[2]);
+        const FixScale fc = fix_scale(8.f * gb);
+        const FixScale fp = fix_scale(24.f * gb * pb * fmaxf(width_f, height_f) * wb);
+        const bool finite = fc.finite && fp.finite;
 
-        // ---- background gradient, :143-147 ----
+        const int32_t face_here = inside ? s_vis[py_l][px_l] : -1;
+        const int slot_here = inside ? (int)s_slot[py_l][px_l] : -1;
+        const Target t_here = make_target(slot_here, lane);
+        const float4 fh4 = s_frag[py_l][px_l];
+
+        // ---- background gradient (:143-147) and colour gradients (:135-142) of the pass's channels ----
         if (inside) {
-            float* gb = p.grad_background + pix * C + c_begin;
+            float* gbk = p.grad_background + pix * C + c0;
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                if (c < G) gb[c] = face_here >= 0 ? 0.f : gch[c];
+            for (int c = 0; c < PC; ++c)
+                if (c < nch) gbk[c] = face_here >= 0 ? 0.f : gch[c];
+        }
+        {
+            const float hb[3] = {fh4.x, fh4.y, fh4.z};
+            float cv[3 * PC];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int c = 0; c < PC; ++c)
+                    cv[k * PC + c] = quad_reduce(t_here, (face_here >= 0 && c < nch) ? gch[c] * hb[k] : 0.f);
+            if (finite && slot_here != -2) {
+                fix_add<3 * PC>(s_acc, t_here, 9, cv, fc.to_fix);
+            } else if (face_here >= 0 && (t_here.active || slot_here == -2)) {
+                // table full, or inf / NaN in the tile: the reference's direct float atomics
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int c = 0; c < PC; ++c)
+                        if (c < nch) atomicAdd(&grad_vertex_colors[(size_t)recs[face_here].vid[k] * C + c0 + c], cv[k * PC + c]);
+            }
         }
 
-        // ---- dilation, :155-194: which pixel's (barycentric, indices, clip_w) this pixel uses ----
-        int cy_l = py_l, cx_l = px_l;  // position (in the halo'd tile) of the fragment used
-        bool dilated = false;
-        if (interior) {
-            float l1x, l1y;
-            if (G == 1 && q1_intended) {
-                l1x = fabsf(sx[0]); l1y = fabsf(sy[0]);
-            } else {
-                l1x = (fabsf(sx[0]) + fabsf(sx[1])) + fabsf(sx[2]);
-                l1y = (fabsf(sy[0]) + fabsf(sy[1])) + fabsf(sy[2]);
-            }
-            int off_x = l1x > l1y ? 1 : 0, off_y = l1x > l1y ? 0 : 1;
-            if (((x_in_frame + y_in_frame) & 1) == 1) { off_x = -off_x; off_y = -off_y; }
-            const float w_here = s_frag[py_l][px_l].w;
-            const int s_h = slot_here;
+        // ---- channel groups of the pass: Scharr, dilation, position gradients ----
+        for (int cg = 0; cg < nch;) {
+            const int c_begin = c0 + cg;
+            const int G = (c_begin + 3 <= C) ? 3 : 1;
+            const bool alias = (G == 1) && !q1_intended;  // quirk Q1: "channels" 1,2 of a 1-channel tensor
+
+            // Scharr, :126-127 (negative-offset minus positive-offset; offset_y is up)
+            float sx[3], sy[3];
 #pragma unroll
-            for (int attempt = 0; attempt < 2; ++attempt) {
-                if (dilated) break;
-                // the reference offsets in GL buffer orientation (y up): tensor row = y - offset_y
-                const int ny = py_l - (attempt == 0 ? off_y : -off_y), nx = px_l + (attempt == 0 ? off_x : -off_x);
-                const int32_t face_off = s_vis[ny][nx];
-                if (face_off >= 0 && face_off != face_here) {
-                    // index triples: equal faces have equal triples; distinct faces are compared by vertex index
-                    const int s_o = s_slot[ny][nx];
-                    bool differs = true;
-                    if (face_here >= 0) {
-                        int a0, a1, a2, b0, b1, b2;
-                        if (s_h >= 0) { a0 = s_vid[s_h][0]; a1 = s_vid[s_h][1]; a2 = s_vid[s_h][2]; }
-                        else { a0 = recs[face_here].vid[0]; a1 = recs[face_here].vid[1]; a2 = recs[face_here].vid[2]; }
-                        if (s_o >= 0) { b0 = s_vid[s_o][0]; b1 = s_vid[s_o][1]; b2 = s_vid[s_o][2]; }
-                        else { b0 = recs[face_off].vid[0]; b1 = recs[face_off].vid[1]; b2 = recs[face_off].vid[2]; }
-                        differs = a0 != b0 || a1 != b1 || a2 != b2;
-                    }
-                    if (differs && w_here > s_frag[ny][nx].w) {  // :165
-                        cy_l = ny; cx_l = nx;
-                        dilated = true;
+            for (int ch = 0; ch < 3; ++ch) {
+                float t[3][3];
+                const bool real = ch < G;
+                const bool aliased = !real && alias && interior;
+                if (real || aliased) {
+#pragma unroll
+                    for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+                        for (int ox = -1; ox <= 1; ++ox) {
+                            if (ox == 0 && oy == 0) { t[1][1] = 0.f; continue; }
+                            float v;
+                            if (real) {
+                                v = s_pix[cg + ch][py_l - oy][px_l + ox];
+                            } else {
+                                // element (pixel + ch) of the flattened [B,H,W,1] slice; interior pixel, so
+                                // the tap itself is unclamped
+                                const int cc = x_in_frame + ox + ch;
+                                if (cc <= W - 1) {
+                                    v = s_pix[cg][py_l - oy][px_l + ox + ch];
+                                } else {
+                                    size_t m = (size_t)iib * frame + (size_t)(y_in_frame - oy) * W + cc;
+                                    if (m > total_pix - 1) m = total_pix - 1;
+                                    v = p.pixels[m * C + c_begin];
+                                }
+                            }
+                            t[oy + 1][ox + 1] = v;
+                        }
+#define AT(ox, oy) t[(oy) + 1][(ox) + 1]
+                    float d1 = ((AT(-1, -1) + AT(-1, +1)) - AT(+1, -1)) - AT(+1, +1);
+                    float d2 = AT(-1, 0) - AT(+1, 0);
+                    float m1 = d1 * (3.f / 32.f), m2 = d2 * (10.f / 32.f);
+                    sx[ch] = m1 + m2;
+                    d1 = ((AT(-1, -1) + AT(+1, -1)) - AT(-1, +1)) - AT(+1, +1);
+                    d2 = AT(0, -1) - AT(0, +1);
+                    m1 = d1 * (3.f / 32.f); m2 = d2 * (10.f / 32.f);
+                    sy[ch] = m1 + m2;
+#undef AT
+                } else {
+                    sx[ch] = 0.f; sy[ch] = 0.f;
+                }
+            }
+
+            // dilation, :155-194: which pixel's (barycentric, indices, clip_w) this pixel uses
+            int cy_l = py_l, cx_l = px_l;  // position (in the halo'd tile) of the fragment used
+            bool dilated = false;
+            if (interior) {
+                float l1x, l1y;
+                if (G == 1 && q1_intended) {
+                    l1x = fabsf(sx[0]); l1y = fabsf(sy[0]);
+                } else {
+                    l1x = (fabsf(sx[0]) + fabsf(sx[1])) + fabsf(sx[2]);
+                    l1y = (fabsf(sy[0]) + fabsf(sy[1])) + fabsf(sy[2]);
+                }
+                int off_x = l1x > l1y ? 1 : 0, off_y = l1x > l1y ? 0 : 1;
+                if (((x_in_frame + y_in_frame) & 1) == 1) { off_x = -off_x; off_y = -off_y; }
+                const float w_here = fh4.w;
+#pragma unroll
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    if (dilated) break;
+                    // the reference offsets in GL buffer orientation (y up): tensor row = y - offset_y
+                    const int ny = py_l - (attempt == 0 ? off_y : -off_y), nx = px_l + (attempt == 0 ? off_x : -off_x);
+                    const int32_t face_off = s_vis[ny][nx];
+                    if (face_off >= 0 && face_off != face_here) {
+                        // index triples: equal faces have equal triples; distinct faces are compared by vertex index
+                        const int s_o = s_slot[ny][nx];
+                        bool differs = true;
+                        if (face_here >= 0) {
+                            int a0, a1, a2, b0, b1, b2;
+                            if (slot_here >= 0) { a0 = s_vid[slot_here][0]; a1 = s_vid[slot_here][1]; a2 = s_vid[slot_here][2]; }
+                            else { a0 = recs[face_here].vid[0]; a1 = recs[face_here].vid[1]; a2 = recs[face_here].vid[2]; }
+                            if (s_o >= 0) { b0 = s_vid[s_o][0]; b1 = s_vid[s_o][1]; b2 = s_vid[s_o][2]; }
+                            else { b0 = recs[face_off].vid[0]; b1 = recs[face_off].vid[1]; b2 = recs[face_off].vid[2]; }
+                            differs = a0 != b0 || a1 != b1 || a2 != b2;
+                        }
+                        if (differs && w_here > s_frag[ny][nx].w) {  // :165
+                            cy_l = ny; cx_l = nx;
+                            dilated = true;
+                        }
                     }
                 }
             }
-        }
 
-        if (p.debug_thingy && c_begin == 0 && inside) {  // :150-151,172
-            float* dbg = p.debug_thingy + pix * 3;
-            dbg[0] = dilated ? 1.e-2f : 0.f;
-            for (int ch = 1; ch <= 2; ++ch) {
-                size_t m = pix * G + ch;
-                if (m > total_pix * G - 1) m = total_pix * G - 1;
-                dbg[ch] = p.grad_pixels[(m / G) * C + c_begin + (m % G)];  // element m of the [B,H,W,G] slice
+            if (p.debug_thingy && c_begin == 0 && inside) {  // :150-151,172
+                float* dbg = p.debug_thingy + pix * 3;
+                dbg[0] = dilated ? 1.e-2f : 0.f;
+                for (int ch = 1; ch <= 2; ++ch) {
+                    size_t m = pix * G + ch;
+                    if (m > total_pix * G - 1) m = total_pix * G - 1;
+                    dbg[ch] = p.grad_pixels[(m / G) * C + c_begin + (m % G)];  // element m of the [B,H,W,G] slice
+                }
             }
-        }
 
-        // ---- per-pixel contributions: colour (:135-142) and position (:196-232) ----
-        const int32_t face_cur = inside ? s_vis[cy_l][cx_l] : -1;
-        const bool covered = face_cur >= 0;
-        const int slot_cur = covered ? (int)s_slot[cy_l][cx_l] : -1;
-        const Target t_cur = make_target(slot_cur, lane);
-        const float4 fc4 = s_frag[cy_l][cx_l];
-        const float cb[3] = {fc4.x, fc4.y, fc4.z};
-        int vid_c[3] = {0, 0, 0};
-        if (covered) {
-            if (slot_cur >= 0) { vid_c[0] = s_vid[slot_cur][0]; vid_c[1] = s_vid[slot_cur][1]; vid_c[2] = s_vid[slot_cur][2]; }
-            else { vid_c[0] = recs[face_cur].vid[0]; vid_c[1] = recs[face_cur].vid[1]; vid_c[2] = recs[face_cur].vid[2]; }
-        }
-        float dL_dx = 0.f, dL_dy = 0.f;
+            // position gradients, :196-232
+            const int32_t face_cur = inside ? s_vis[cy_l][cx_l] : -1;
+            const bool covered = face_cur >= 0;
+            const int slot_cur = covered ? (int)s_slot[cy_l][cx_l] : -1;
+            const Target t_cur = make_target(slot_cur, lane);
+            const float4 fc4 = s_frag[cy_l][cx_l];
+            const float cb[3] = {fc4.x, fc4.y, fc4.z};
+            float dL_dx = 0.f, dL_dy = 0.f;
 #pragma unroll
-        for (int channel = 0; channel < 3; ++channel) {
-            if (channel < G) {
-                float m = gch[channel] * sx[channel];
-                dL_dx = dL_dx + m;
-                m = gch[channel] * sy[channel];
-                dL_dy = dL_dy + m;
+            for (int channel = 0; channel < 3; ++channel) {
+                if (channel < G) {
+                    const float gcv = (cg + channel == 0) ? gch[0] : (cg + channel == 1) ? gch[1] : (cg + channel == 2) ? gch[2] : gch[3];
+                    float m = gcv * sx[channel];
+                    dL_dx = dL_dx + m;
+                    m = gcv * sy[channel];
+                    dL_dy = dL_dy + m;
+                }
             }
-        }
-        float clip_x = 0.f, clip_y = 0.f;
-        if (covered) {
+            // clip-space x,y of the fragment used (:210-215 sums b_k * vertex_k.xy; perspective-correct
+            // barycentrics make that sum the fragment's own clip position = its NDC position times clip_w,
+            // so no vertex gather is needed; agrees to float rounding)
+            const float clip_w = fc4.w;
+            const float ndc_x = ((float)(tx0 + cx_l - 1) + 0.5f) * (2.f / width_f) - 1.f;
+            const float ndc_y = ((float)(H - 1 - (tr0 + cy_l - 1)) + 0.5f) * (2.f / height_f) - 1.f;
+            const float clip_x = ndc_x * clip_w, clip_y = ndc_y * clip_w;
+            // :219-222 with one reciprocal instead of four divisions
+            const float rcp_w = 1.0f / clip_w;
+            const float d_xview_by_xclip = (.5f * width_f) * rcp_w;
+            const float d_yview_by_yclip = (.5f * height_f) * rcp_w;
+            const float rcp_ww = rcp_w * rcp_w;
+            const float d_xview_by_wclip = ((-.5f * width_f) * clip_x) * rcp_ww;
+            const float d_yview_by_wclip = ((-.5f * height_f) * clip_y) * rcp_ww;
+            float pv[9];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float2 vxy = *reinterpret_cast<const float2*>(vertices + (size_t)vid_c[k] * 4);
-                float m = cb[k] * vxy.x;
-                clip_x = clip_x + m;
-                m = cb[k] * vxy.y;
-                clip_y = clip_y + m;
+                const float dLx_b = dL_dx * cb[k];
+                const float dLy_b = dL_dy * cb[k];
+                const float gw1 = dLx_b * d_xview_by_wclip, gw2 = dLy_b * d_yview_by_wclip;
+                pv[k * 3 + 0] = quad_reduce(t_cur, covered ? dLx_b * d_xview_by_xclip : 0.f);
+                pv[k * 3 + 1] = quad_reduce(t_cur, covered ? dLy_b * d_yview_by_yclip : 0.f);
+                pv[k * 3 + 2] = quad_reduce(t_cur, covered ? gw1 + gw2 : 0.f);
             }
-        }
-        const float clip_w = fc4.w;
-        const float d_xview_by_xclip = (.5f * width_f) / clip_w;
-        const float d_yview_by_yclip = (.5f * height_f) / clip_w;
-        const float ww = clip_w * clip_w;
-        const float d_xview_by_wclip = ((-.5f * width_f) * clip_x) / ww;
-        const float d_yview_by_wclip = ((-.5f * height_f) * clip_y) / ww;
-
-        const float4 fh4 = s_frag[py_l][px_l];
-        const float hb[3] = {fh4.x, fh4.y, fh4.z};
-        float val[NVAL];  // [0..8] position (k*3 + {x,y,w}), [9..17] colour (9 + k*3 + c)
+            if (finite && slot_cur != -2) {
+                fix_add<9>(s_acc, t_cur, 0, pv, fp.to_fix);
+            } else if (covered && (t_cur.active || slot_cur == -2)) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float dLx_b = dL_dx * cb[k];
-            const float dLy_b = dL_dy * cb[k];
-            const float gw1 = dLx_b * d_xview_by_wclip, gw2 = dLy_b * d_yview_by_wclip;
-            val[k * 3 + 0] = covered ? dLx_b * d_xview_by_xclip : 0.f;
-            val[k * 3 + 1] = covered ? dLy_b * d_yview_by_yclip : 0.f;
-            val[k * 3 + 2] = covered ? gw1 + gw2 : 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) val[9 + k * 3 + c] = (face_here >= 0 && c < G) ? gch[c] * hb[k] : 0.f;
-        }
-
-        // faces that found no slot (table full): the reference's direct atomics
-        if (slot_cur == -2) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float* gv = grad_vertices + (size_t)vid_c[k] * 4;
-                atomicAdd(gv + 0, val[k * 3 + 0]);
-                atomicAdd(gv + 1, val[k * 3 + 1]);
-                atomicAdd(gv + 3, val[k * 3 + 2]);
+                for (int k = 0; k < 3; ++k) {
+                    float* gv = grad_vertices + (size_t)recs[face_cur].vid[k] * 4;
+                    atomicAdd(gv + 0, pv[k * 3 + 0]);
+                    atomicAdd(gv + 1, pv[k * 3 + 1]);
+                    atomicAdd(gv + 3, pv[k * 3 + 2]);
+                }
             }
+            cg += G;
         }
-        if (slot_here == -2) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    if (c < G) atomicAdd(&grad_vertex_colors[(size_t)recs[face_here].vid[k] * C + c_begin + c], val[9 + k * 3 + c]);
-        }
-
-        GMARK();  // per-pixel math done
-        // ---- quad pre-reduction and the tile-wide magnitude of what will be added ----
-        uint32_t mp = 0u, mc = 0u;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            val[i] = quad_reduce(t_cur, val[i]);
-            if (t_cur.active) mp = max(mp, __float_as_uint(fabsf(val[i])));
-            val[9 + i] = quad_reduce(t_here, val[9 + i]);
-            if (t_here.active) mc = max(mc, __float_as_uint(fabsf(val[9 + i])));
-        }
-        mp = wave_max_u32(mp);
-        mc = wave_max_u32(mc);
-        if (lane == 0) {
-            if (mp) atomicMax(&s_max[0], mp);
-            if (mc) atomicMax(&s_max[1], mc);
-        }
-        __syncthreads();
-        GMARK();  // max barrier
-
-        // ---- fixed-point accumulation (integer LDS atomics: exact, order independent) ----
-        const FixScale fp = fix_scale(s_max[0]), fc = fix_scale(s_max[1]);
-        if (fp.finite) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) fix_add(s_acc, t_cur, i, val[i], fp.to_fix);
-        } else if (t_cur.active) {  // inf / NaN somewhere in the tile: float atomics keep IEEE semantics
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float* gv = grad_vertices + (size_t)vid_c[k] * 4;
-                atomicAdd(gv + 0, val[k * 3 + 0]);
-                atomicAdd(gv + 1, val[k * 3 + 1]);
-                atomicAdd(gv + 3, val[k * 3 + 2]);
-            }
-        }
-        if (fc.finite) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) fix_add(s_acc, t_here, 9 + i, val[9 + i], fc.to_fix);
-        } else if (t_here.active) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    if (c < G) atomicAdd(&grad_vertex_colors[(size_t)s_vid[slot_here][k] * C + c_begin + c], val[9 + k * 3 + c]);
-        }
-        GMARK();  // accumulated
+        GMARK();  // 5 accumulated
         __syncthreads();
 
-        // ---- flush: one global atomic per (face, vertex, component) for the whole tile ----
+        // ---- flush: one global atomic per (face, vertex, component) for the whole tile and pass ----
         for (int e = tid; e < MAX_SLOTS * NVAL; e += GTHREADS) {
             const int slot = e / NVAL, v = e - slot * NVAL;
             if (s_key[slot] < 0) continue;
@@ -510,14 +521,17 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                 const int k = v / 3, comp = v - k * 3;
                 atomicAdd(&grad_vertices[(size_t)s_vid[slot][k] * 4 + (comp == 2 ? 3 : comp)], f);
             } else {
-                const int k = (v - 9) / 3, c = (v - 9) - k * 3;
-                if (c < G) atomicAdd(&grad_vertex_colors[(size_t)s_vid[slot][k] * C + c_begin + c], f);
+                const int k = (v - 9) / PC, c = (v - 9) - k * PC;
+                if (c < nch) atomicAdd(&grad_vertex_colors[(size_t)s_vid[slot][k] * C + c0 + c], f);
             }
         }
-        GMARK();  // flushed
-        __syncthreads();
-        if (tid < 2) s_max[tid] = 0u;  // ordered before the next group's atomicMax by its staging barrier
-        c_begin += G;
+        GMARK();  // 6 flushed
+        c0 += nch;
+        if (c0 < C) {
+            __syncthreads();
+            if (tid < 2) s_bound[tid] = 0u;  // |grad_pixels| and |pixels| bounds are per pass; 1/w is per tile
+            __syncthreads();
+        }
     }
 #ifdef DIRT_TRACE
     if (lane == 0 && g_trace_grad) {
