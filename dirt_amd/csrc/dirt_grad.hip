@@ -49,10 +49,12 @@ extern "C" void dirt_debug_set_trace_grad(void* p)
 
 constexpr int GW = 32, GH = 16;        // tile = 32 x 16 pixels, one pixel per lane
 constexpr int GTHREADS = 512;          // 8 waves = 4 x 2 blocks of 8 x 8 pixels
-constexpr int PW = GW + 4;             // staged `pixels` columns: x0-1 .. x0+34 (halo + 2 for the Q1 alias taps)
+constexpr int PWU = GW + 4;            // staged `pixels` columns: x0-1 .. x0+34 (halo + 2 for the Q1 alias taps)
+constexpr int PW = 40;                 // ... padded: row stride = 8 (mod 32) dwords keeps an 8x8 block's reads conflict free
 constexpr int PH = GH + 2;             // staged rows: y0-1 .. y0+16
-constexpr int VW = GW + 2;             // visibility tile with a 1-pixel halo
-constexpr int COPIES = 2;              // accumulator replicas per (slot, value)
+constexpr int VWU = GW + 2;            // visibility tile with a 1-pixel halo
+constexpr int VW = 40;                 // ... padded likewise (32 (mod 64) dwords for the float4 rows)
+constexpr int COPIES = 4;              // accumulator replicas per (slot, value)
 constexpr int MAX_SLOTS = 64;          // slot table capacity (LDS)
 constexpr int PC = 4;                  // channels per pass: whole channel groups that fit in 4 channels
 constexpr int NVAL = 9 + 3 * PC;       // 9 position values (3 vertices x {x,y,w}) + 3 vertices x PC colour values
@@ -236,8 +238,8 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
     //      csrc/rasterise_grad_egl.cpp:442-445.  Halo positions outside the frame are clamped; they
     //      are only ever consulted for interior pixels, whose neighbours are inside the frame. ----
     float rcpw_max = 0.f;
-    for (int i = tid; i < PH * VW; i += GTHREADS) {
-        const int vy = i / VW, vx = i - vy * VW;
+    for (int i = tid; i < PH * VWU; i += GTHREADS) {
+        const int vy = i / VWU, vx = i - vy * VWU;
         const int rr = min(max(tr0 + vy - 1, 0), H - 1), xx = min(max(tx0 + vx - 1, 0), W - 1);
         const int32_t face = vis[(size_t)rr * W + xx];
         float4 fr = make_float4(-1.f, -1.f, -1.f, INFINITY);
@@ -269,13 +271,40 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
         }
         // ---- stage the pass's channels of the pixels tile (+halo), edge clamped: at(), :113-124 ----
         float pmax = 0.f, gmax = 0.f;
-        for (int i = tid; i < nch * PH * PW; i += GTHREADS) {
-            const int ch = i / (PH * PW), rem = i - ch * (PH * PW);
-            const int yy = rem / PW, xx = rem - yy * PW;
-            const int cy = min(max(tr0 + yy - 1, 0), H - 1), cx = min(max(tx0 + xx - 1, 0), W - 1);
-            const float v = pixels[((size_t)cy * W + cx) * C + c0 + ch];
-            s_pix[ch][yy][xx] = v;
-            pmax = fmaxf(pmax, fabsf(v));
+        {
+            // two positions per thread (PH * PWU = 648 <= 2 * 512); every load is issued before the first
+            // LDS store so the tile costs one memory latency
+            float v[2][PC];
+            int pos[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + j * GTHREADS;
+                pos[j] = i < PH * PWU ? i : -1;
+                const int ii = min(i, PH * PWU - 1);
+                const int yy = ii / PWU, xx = ii - yy * PWU;
+                const int cy = min(max(tr0 + yy - 1, 0), H - 1), cx = min(max(tx0 + xx - 1, 0), W - 1);
+                const float* src = pixels + ((size_t)cy * W + cx) * C + c0;
+                if (nch == 4 && (C & 3) == 0 && p.pixels_aligned16) {
+                    const float4 q = *reinterpret_cast<const float4*>(src);  // c0 is a multiple of 4 here
+                    v[j][0] = q.x; v[j][1] = q.y; v[j][2] = q.z; v[j][3] = q.w;
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < PC; ++ch) v[j][ch] = ch < nch ? src[ch] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (pos[j] < 0) continue;
+                const int yy = pos[j] / PWU, xx = pos[j] - yy * PWU;
+#pragma unroll
+                for (int ch = 0; ch < PC; ++ch) {
+                    if (ch < nch) {
+                        s_pix[ch][yy][xx] = v[j][ch];
+                        pmax = fmaxf(pmax, fabsf(v[j][ch]));
+                        if (!(v[j][ch] == v[j][ch])) pmax = INFINITY;
+                    }
+                }
+            }
         }
         float gch[PC];
 #pragma unroll
@@ -283,8 +312,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
             gch[c] = (c < nch) ? g_here[c0 + c] : 0.f;
             gmax = fmaxf(gmax, fabsf(gch[c]));
         }
-        // NaNs do not survive fmaxf: fold them in explicitly so the inf/NaN fallback sees them
-        if (!(pmax == pmax)) pmax = INFINITY;
+        // (NaNs do not survive fmaxf: they are folded in explicitly so the inf/NaN fallback sees them)
         {
             bool gnan = false;
 #pragma unroll
@@ -548,6 +576,7 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     p.tiles_x = (p.W + GW - 1) / GW;
     p.tiles_y = (p.H + GH - 1) / GH;
     p.nslots = MAX_SLOTS;
+    p.pixels_aligned16 = (reinterpret_cast<uintptr_t>(p.pixels) & 15u) == 0 ? 1 : 0;
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.B);
     hipLaunchKernelGGL(grad_kernel, grid, dim3(GTHREADS), 0, stream, p);
     return hipGetLastError();
