@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <vector>
 #include "../../include/dirt_hip.h"
 #include "dirt_launch.h"
@@ -135,6 +136,15 @@ int check_workspace(const char* who, const Workspace& w, void* workspace, size_t
     return DIRT_OK;
 }
 
+// Kernels use 16-byte loads / stores on these tensors (float4 vertices, HWC pixels with C % 4 == 0).
+int check_aligned(const char* who, std::initializer_list<const void*> ptrs)
+{
+    for (const void* q : ptrs)
+        if ((reinterpret_cast<uintptr_t>(q) & 15u) != 0)
+            return fail(DIRT_E_INVALID_ARGUMENT, "%s: tensor pointers must be 16-byte aligned", who);
+    return DIRT_OK;
+}
+
 #define HIP_TRY(who, expr)                                                                         \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \
@@ -209,6 +219,8 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
     if (!background || !pixels) return fail(DIRT_E_INVALID_ARGUMENT, "%s: background / pixels is NULL", who);
     if ((V > 0 && (!vertices || !vertex_colors)) || (F > 0 && !faces))
         return fail(DIRT_E_INVALID_ARGUMENT, "%s: vertices / vertex_colors / faces is NULL", who);
+    rc = check_aligned(who, {background, vertices, vertex_colors, faces, pixels});
+    if (rc) return rc;
     const Workspace w = carve(B, F, H, W);
     rc = check_workspace(who, w, workspace, workspace_bytes);
     if (rc) return rc;
@@ -241,6 +253,8 @@ int dirt_rasterise_visibility(const float* vertices, const int32_t* faces, int32
     if (!face_id) return fail(DIRT_E_INVALID_ARGUMENT, "%s: face_id is NULL", who);
     if ((V > 0 && !vertices) || (F > 0 && !faces))
         return fail(DIRT_E_INVALID_ARGUMENT, "%s: vertices / faces is NULL", who);
+    rc = check_aligned(who, {vertices, faces, face_id});
+    if (rc) return rc;
     const Workspace w = carve(B, F, H, W);
     rc = check_workspace(who, w, workspace, workspace_bytes);
     if (rc) return rc;
@@ -277,6 +291,8 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
         return fail(DIRT_E_INVALID_ARGUMENT, "%s: pixels / grad_pixels / grad_background is NULL", who);
     if ((V > 0 && (!vertices || !grad_vertices || !grad_vertex_colors)) || (F > 0 && !faces))
         return fail(DIRT_E_INVALID_ARGUMENT, "%s: vertices / faces / grad_vertices / grad_vertex_colors is NULL", who);
+    rc = check_aligned(who, {vertices, faces, pixels, grad_pixels, grad_background, grad_vertices, grad_vertex_colors});
+    if (rc) return rc;
     const Workspace w = carve(B, F, H, W);
     rc = check_workspace(who, w, workspace, workspace_bytes);
     if (rc) return rc;

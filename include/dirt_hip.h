@@ -8,7 +8,8 @@
  * library with ctypes -- see INTEGRATION.md for the stub.
  *
  * Conventions shared by every call
- *   - all tensors are dense, row-major, float32 except `faces` (int32); device pointers;
+ *   - all tensors are dense, row-major, float32 except `faces` (int32); device pointers, 16-byte
+ *     aligned (torch / hipMalloc allocations are);
  *   - background / pixels / grad_* images are [B,H,W,C], top row first (README.md:183);
  *     vertices [B,V,4] are OpenGL clip-space (x,y,z,w); vertex_colors [B,V,C]; faces [B,F,3];
  *   - `workspace` is caller-owned device scratch of at least dirt_workspace_bytes(...) bytes,

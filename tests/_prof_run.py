@@ -1,0 +1,14 @@
+import sys, os; sys.path.insert(0, '.')
+import numpy as np, torch
+from dirt_amd import scenes, rasterise_ops as ops
+dev = torch.device('cuda:0')
+cfg = sys.argv[1] if len(sys.argv) > 1 else 'K3'
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+s = scenes.config_scene(cfg)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+H, W, C = s['height'], s['width'], s['channels']
+bg, v, vc, f, g = t(s['background'][None]), t(s['vertices'][None]), t(s['vertex_colors'][None]), t(s['faces'][None]), t(s['grad_pixels'][None])
+for it in range(n):
+    px = ops._op_rasterise(bg, v, vc, f, H, W, C)
+    out = ops._op_rasterise_grad(v, f, px, g, H, W, C)
+torch.cuda.synchronize()

@@ -1,0 +1,65 @@
+"""Turns gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the tracked summaries under profiles/:
+   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python bench.py --steps 50 --warmup 10`
+   profiles/<tag>_pmc.txt            per-kernel PMC averages (separate --pmc passes)
+   profiles/<tag>_bench.json         the bench line of the same build
+   profiles/pmc_traffic.json         HBM bytes per launch per kernel, FETCH_SIZE doubled as
+                                     /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950
+usage: python tools/summarise_profiles.py r01 [config]"""
+import collections
+import csv
+import glob
+import io
+import json
+import os
+import shutil
+import sys
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import pmc_summary  # noqa: E402
+
+SLOT = {'grad_kernel': 'grad_kernel', 'raster_kernel<0>': 'raster_kernel<shade>', 'raster_kernel<1>': 'raster_kernel<visibility>',
+        'setup_kernel': 'setup_kernel', 'fill_kernel': 'fill_kernel', 'zero_kernel': 'zero_kernel'}
+
+
+def counter(path, name):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == name:
+            k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('dirt::', '')
+            agg[k].append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main():
+    tag = sys.argv[1]
+    config = sys.argv[2] if len(sys.argv) > 2 else 'K3'
+    src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
+    dst = os.path.join(ROOT, 'profiles')
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, 'trace', 'trace_kernel_stats.csv'), os.path.join(dst, tag + '_kernel_stats.csv'))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        sys.argv = ['pmc_summary'] + [os.path.join(src, d) for d in ('trace', 'pmc_sq', 'pmc_lds', 'pmc_fetch', 'pmc_write', 'pmc_l2')]
+        pmc_summary.main()
+    open(os.path.join(dst, tag + '_pmc.txt'), 'w').write(buf.getvalue().replace(ROOT + '/', ''))
+    line = [l for l in open(os.path.join(src, 'bench.json')).read().splitlines() if l.startswith('{')][-1]
+    json.dump(json.loads(line), open(os.path.join(dst, tag + '_bench.json'), 'w'), indent=1)
+    fetch = counter(glob.glob(os.path.join(src, 'pmc_fetch', '*counter_collection.csv'))[0], 'FETCH_SIZE')
+    write = counter(glob.glob(os.path.join(src, 'pmc_write', '*counter_collection.csv'))[0], 'WRITE_SIZE')
+    traffic = {}
+    for k in fetch:
+        # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
+        traffic[SLOT.get(k, k)] = int(2 * fetch[k] * 1024 + write.get(k, 0) * 1024)
+    path = os.path.join(dst, 'pmc_traffic.json')
+    allt = json.load(open(path)) if os.path.exists(path) else {}
+    allt[config] = traffic
+    allt['_note'] = ('HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes); the factor 2 is the gfx950 FETCH_SIZE '
+                     'correction of MI355X_MICROARCH.md (calibrated there for wide coalesced reads; narrower accesses are uncalibrated)')
+    json.dump(allt, open(path, 'w'), indent=1)
+    print(json.dumps(traffic, indent=1))
+
+
+if __name__ == '__main__':
+    main()
