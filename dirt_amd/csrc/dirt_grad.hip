@@ -108,7 +108,7 @@ __device__ inline int slot_insert(int32_t* keys, int nslots, int face)
 {
     uint32_t h = ((uint32_t)face * 2654435761u) % (uint32_t)nslots;
     for (int probe = 0; probe < nslots; ++probe) {
-        const int32_t cur = reinterpret_cast<volatile int32_t*>(keys)[h];
+        const int32_t cur = __hip_atomic_load(keys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == face) return (int)h;
         if (cur == -1) {
             const int32_t prev = atomicCAS(&keys[h], -1, face);
@@ -180,6 +180,53 @@ __device__ __forceinline__ void fix_add(unsigned long long* acc, const Target& t
             atomicAdd(a + i * COPIES, (unsigned long long)(long long)q);
         }
     }
+}
+
+// Index-triple comparison of two faces through their records (only when the slot table is full).
+__device__ __noinline__ bool triple_differs_global(const FaceRec* __restrict__ recs, int fa, int fb)
+{
+    return recs[fa].vid[0] != recs[fb].vid[0] || recs[fa].vid[1] != recs[fb].vid[1] || recs[fa].vid[2] != recs[fb].vid[2];
+}
+
+// Scharr responses of one channel at the pixel `c` points to (row stride PW), from the staged tile:
+// csrc/rasterise_grad_egl.cu:126-127, operation for operation (negative-offset minus positive-offset,
+// offset_y is up = the previous tensor row).
+__device__ __forceinline__ void scharr_taps(const float* c, float& sx, float& sy)
+{
+    const float mm = c[PW - 1], m0 = c[-1], mp = c[-PW - 1];     // at(-1,-1) at(-1,0) at(-1,+1)
+    const float zm = c[PW], zp = c[-PW];                         // at(0,-1)           at(0,+1)
+    const float pm = c[PW + 1], p0 = c[1], pp = c[-PW + 1];      // at(+1,-1) at(+1,0) at(+1,+1)
+    float d1 = ((mm + mp) - pm) - pp;
+    float d2 = m0 - p0;
+    float m1 = d1 * (3.f / 32.f), m2 = d2 * (10.f / 32.f);
+    sx = m1 + m2;
+    d1 = ((mm + pm) - mp) - pp;
+    d2 = zm - zp;
+    m1 = d1 * (3.f / 32.f); m2 = d2 * (10.f / 32.f);
+    sy = m1 + m2;
+}
+
+// The same from global memory for an aliased (quirk Q1) channel whose taps run past the end of the
+// image row: `centre` is the flat pixel index of the tap centre in the [B,H,W] slice; reads past the end
+// of the tensor are clamped to its last element (undefined in the reference).  Rare: kept out of line.
+__device__ __noinline__ float2 scharr_taps_wrapped(const float* __restrict__ pixels, size_t total_pix, size_t centre, int W,
+                                                   int C, int c)
+{
+    float sx, sy;
+    auto at = [&](int ox, int oy) {
+        size_t m = centre + (size_t)ox - (size_t)((long long)oy * W);  // offset_y up = previous row
+        if (m > total_pix - 1) m = total_pix - 1;
+        return pixels[m * C + c];
+    };
+    float d1 = ((at(-1, -1) + at(-1, +1)) - at(+1, -1)) - at(+1, +1);
+    float d2 = at(-1, 0) - at(+1, 0);
+    float m1 = d1 * (3.f / 32.f), m2 = d2 * (10.f / 32.f);
+    sx = m1 + m2;
+    d1 = ((at(-1, -1) + at(+1, -1)) - at(-1, +1)) - at(+1, +1);
+    d2 = at(0, -1) - at(0, +1);
+    m1 = d1 * (3.f / 32.f); m2 = d2 * (10.f / 32.f);
+    sy = m1 + m2;
+    return make_float2(sx, sy);
 }
 
 __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
@@ -386,44 +433,23 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
             float sx[3], sy[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                float t[3][3];
-                const bool real = ch < G;
-                const bool aliased = !real && alias && interior;
-                if (real || aliased) {
+                sx[ch] = 0.f; sy[ch] = 0.f;
+                if (ch < G) scharr_taps(&s_pix[cg + ch][py_l][px_l], sx[ch], sy[ch]);
+            }
+            if (alias) {
+                // quirk Q1: "channels" 1,2 of a 1-channel group = elements (pixel + ch) of the flattened
+                // [B,H,W,1] slice.  Only the L1 norms of interior pixels use them, and for an interior
+                // pixel the taps are unclamped: column + ch, which is staged unless it runs past the end
+                // of the image row (then it wraps to the next row: read from global memory).
 #pragma unroll
-                    for (int oy = -1; oy <= 1; ++oy)
-#pragma unroll
-                        for (int ox = -1; ox <= 1; ++ox) {
-                            if (ox == 0 && oy == 0) { t[1][1] = 0.f; continue; }
-                            float v;
-                            if (real) {
-                                v = s_pix[cg + ch][py_l - oy][px_l + ox];
-                            } else {
-                                // element (pixel + ch) of the flattened [B,H,W,1] slice; interior pixel, so
-                                // the tap itself is unclamped
-                                const int cc = x_in_frame + ox + ch;
-                                if (cc <= W - 1) {
-                                    v = s_pix[cg][py_l - oy][px_l + ox + ch];
-                                } else {
-                                    size_t m = (size_t)iib * frame + (size_t)(y_in_frame - oy) * W + cc;
-                                    if (m > total_pix - 1) m = total_pix - 1;
-                                    v = p.pixels[m * C + c_begin];
-                                }
-                            }
-                            t[oy + 1][ox + 1] = v;
-                        }
-#define AT(ox, oy) t[(oy) + 1][(ox) + 1]
-                    float d1 = ((AT(-1, -1) + AT(-1, +1)) - AT(+1, -1)) - AT(+1, +1);
-                    float d2 = AT(-1, 0) - AT(+1, 0);
-                    float m1 = d1 * (3.f / 32.f), m2 = d2 * (10.f / 32.f);
-                    sx[ch] = m1 + m2;
-                    d1 = ((AT(-1, -1) + AT(+1, -1)) - AT(-1, +1)) - AT(+1, +1);
-                    d2 = AT(0, -1) - AT(0, +1);
-                    m1 = d1 * (3.f / 32.f); m2 = d2 * (10.f / 32.f);
-                    sy[ch] = m1 + m2;
-#undef AT
-                } else {
-                    sx[ch] = 0.f; sy[ch] = 0.f;
+                for (int ch = 1; ch < 3; ++ch) {
+                    if (x_in_frame + 1 + ch <= W - 1 || !interior) {
+                        scharr_taps(&s_pix[cg][py_l][min(px_l + ch, PW - 2)], sx[ch], sy[ch]);
+                    } else {
+                        const float2 w2 = scharr_taps_wrapped(p.pixels, total_pix,
+                                                              (size_t)iib * frame + (size_t)y_in_frame * W + x_in_frame + ch, W, C, c_begin);
+                        sx[ch] = w2.x; sy[ch] = w2.y;
+                    }
                 }
             }
 
@@ -452,12 +478,11 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                         const int s_o = s_slot[ny][nx];
                         bool differs = true;
                         if (face_here >= 0) {
-                            int a0, a1, a2, b0, b1, b2;
-                            if (slot_here >= 0) { a0 = s_vid[slot_here][0]; a1 = s_vid[slot_here][1]; a2 = s_vid[slot_here][2]; }
-                            else { a0 = recs[face_here].vid[0]; a1 = recs[face_here].vid[1]; a2 = recs[face_here].vid[2]; }
-                            if (s_o >= 0) { b0 = s_vid[s_o][0]; b1 = s_vid[s_o][1]; b2 = s_vid[s_o][2]; }
-                            else { b0 = recs[face_off].vid[0]; b1 = recs[face_off].vid[1]; b2 = recs[face_off].vid[2]; }
-                            differs = a0 != b0 || a1 != b1 || a2 != b2;
+                            if (slot_here >= 0 && s_o >= 0)
+                                differs = s_vid[slot_here][0] != s_vid[s_o][0] || s_vid[slot_here][1] != s_vid[s_o][1] ||
+                                          s_vid[slot_here][2] != s_vid[s_o][2];
+                            else  // a face without a slot (table full): compare through the records
+                                differs = triple_differs_global(recs, face_here, face_off);
                         }
                         if (differs && w_here > s_frag[ny][nx].w) {  // :165
                             cy_l = ny; cx_l = nx;
