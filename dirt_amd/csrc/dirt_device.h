@@ -20,12 +20,11 @@ namespace dirt {
 // with two wide scalar loads.  The first 100 bytes are what the coverage / depth loop needs.
 //
 // Sign folding: for an edge whose on-edge samples are EXCLUDED by the tie rule the three
-// coefficients and zs are stored negated (F_k = -E_k).  The coverage test then is a single
-// `F_k >= 0` compare per edge, xor-ed with the edge's `excl` flag; products F_k*zs_k are unchanged
-// by the double negation, so depth is bit-identical to the unfolded form.
+// coefficients are stored negated (F_k = -E_k).  The coverage test then is a single `F_k >= 0`
+// compare per edge, xor-ed with the edge's `excl` flag.
 struct alignas(128) FaceRec {
     double coef[9];   //   0: (a,b,c) of edges 0,1,2, sign-folded
-    double zs[3];     //  72: clip z_k * inv_det, sign-folded
+    double zp[3];     //  72: depth plane: zn = fma(zp[0], px, fma(zp[1], py, zp[2]))
     uint32_t flags;   //  96: bit k = edge k folded (exclusive); bit 31 = valid
     uint32_t pad0;    // 100
     double inv_det;   // 104: 1/|det|
@@ -105,13 +104,20 @@ __device__ inline bool setup_face(const float* __restrict__ verts, int V, const 
     }
     if (i_min > i_max || j_min > j_max) return false;
 
+    // depth plane from the unfolded coefficients (NDC depth = sum_k E_k * z_k / det is affine in the sample)
+    double zs[3];
+    for (int k = 0; k < 3; ++k) zs[k] = Z[k] * inv_det;
+    {
+        double m0, m1, m2;
+        m0 = a[0] * zs[0]; m1 = a[1] * zs[1]; m2 = a[2] * zs[2]; rec.zp[0] = (m0 + m1) + m2;
+        m0 = b[0] * zs[0]; m1 = b[1] * zs[1]; m2 = b[2] * zs[2]; rec.zp[1] = (m0 + m1) + m2;
+        m0 = c[0] * zs[0]; m1 = c[1] * zs[1]; m2 = c[2] * zs[2]; rec.zp[2] = (m0 + m1) + m2;
+    }
     uint32_t flags = FACE_VALID;
     for (int k = 0; k < 3; ++k) {
         const bool incl = (a[k] > 0.0) || (a[k] == 0.0 && b[k] > 0.0);
-        double zs = Z[k] * inv_det;
-        if (!incl) { a[k] = -a[k]; b[k] = -b[k]; c[k] = -c[k]; zs = -zs; flags |= (1u << k); }
+        if (!incl) { a[k] = -a[k]; b[k] = -b[k]; c[k] = -c[k]; flags |= (1u << k); }
         rec.coef[3 * k + 0] = a[k]; rec.coef[3 * k + 1] = b[k]; rec.coef[3 * k + 2] = c[k];
-        rec.zs[k] = zs;
     }
     rec.flags = flags; rec.pad0 = 0; rec.pad1 = 0;
     rec.inv_det = inv_det;

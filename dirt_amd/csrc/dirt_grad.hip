@@ -232,7 +232,7 @@ __device__ __noinline__ float2 scharr_taps_wrapped(const float* __restrict__ pix
 __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
 {
     __shared__ float s_pix[PC][PH][PW];                              // the pass's channels of `pixels`, edge clamped
-    __shared__ unsigned long long s_acc[MAX_SLOTS * NVAL * COPIES];  // fixed-point partial sums
+    __shared__ __align__(16) unsigned long long s_acc[MAX_SLOTS * NVAL * COPIES];  // fixed-point partial sums
     __shared__ float4 s_frag[PH][VW];                                // (b0,b1,b2,clip_w) of every pixel of the halo'd tile
     __shared__ int32_t s_vis[PH][VW];                                // its front-most face
     __shared__ int16_t s_slot[PH][VW];                               // and that face's slot (-1 none, -2 table full)
@@ -273,9 +273,50 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
     const bool q1_intended = (p.flags & DIRT_FLAG_Q1_INTENDED) != 0;
     const float width_f = (float)W, height_f = (float)H;
 
+    // channels of a pass: whole channel groups (dirt/rasterise_ops.py:148-152) starting at c0 that fit in PC channels
+    auto pass_channels = [&](int c0) {
+        int nch = 0;
+        for (int c = c0; c < C && nch < PC;) {
+            const int G = (c + 3 <= C) ? 3 : 1;
+            if (nch + G > PC) break;
+            nch += G; c += G;
+        }
+        return nch;
+    };
+    // loads of the pass's channels of the pixels tile (+halo), edge clamped (at(), :113-124): two positions per
+    // thread (PH * PWU = 648 <= 2 * 512), every load issued before any use so the tile costs one memory latency
+    auto stage_load = [&](int c0, int nch, float (&v)[2][PC]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ii = min(tid + j * GTHREADS, PH * PWU - 1);
+            const int yy = ii / PWU, xx = ii - yy * PWU;
+            const int cy = min(max(tr0 + yy - 1, 0), H - 1), cx = min(max(tx0 + xx - 1, 0), W - 1);
+            const float* src = pixels + ((size_t)cy * W + cx) * C + c0;
+            if (nch == 4 && (C & 3) == 0 && p.pixels_aligned16) {
+                const float4 q = *reinterpret_cast<const float4*>(src);  // c0 is a multiple of 4 here
+                v[j][0] = q.x; v[j][1] = q.y; v[j][2] = q.z; v[j][3] = q.w;
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < PC; ++ch) v[j][ch] = ch < nch ? src[ch] : 0.f;
+            }
+        }
+    };
+    // the first pass's tile and this pixel's grad_pixels are requested now: their latency overlaps phase A
+    float stage0_v[2][PC];
+    stage_load(0, pass_channels(0), stage0_v);
+    float g0v[PC];
+    {
+        const int nch0 = pass_channels(0);
+#pragma unroll
+        for (int c = 0; c < PC; ++c) g0v[c] = c < nch0 ? g_here[c] : 0.f;
+    }
+
     // ---- init ----
     for (int i = tid; i < MAX_SLOTS; i += GTHREADS) s_key[i] = -1;
-    for (int i = tid; i < MAX_SLOTS * NVAL * COPIES; i += GTHREADS) s_acc[i] = 0ull;
+    {
+        uint4* z = reinterpret_cast<uint4*>(s_acc);  // 16-byte stores
+        for (int i = tid; i < MAX_SLOTS * NVAL * COPIES / 2; i += GTHREADS) z[i] = make_uint4(0, 0, 0, 0);
+    }
     if (tid < 3) s_bound[tid] = 0u;
     __syncthreads();
     GMARK();  // 1 init
@@ -309,54 +350,36 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
     GMARK();  // 2 phase A body
 
     for (int c0 = 0; c0 < C;) {
-        // ---- the pass: whole channel groups (dirt/rasterise_ops.py:148-152) starting at c0 that fit in PC channels ----
-        int nch = 0;
-        for (int c = c0; c < C && nch < PC;) {
-            const int G = (c + 3 <= C) ? 3 : 1;
-            if (nch + G > PC) break;
-            nch += G; c += G;
-        }
+        const int nch = pass_channels(c0);
         // ---- stage the pass's channels of the pixels tile (+halo), edge clamped: at(), :113-124 ----
         float pmax = 0.f, gmax = 0.f;
-        {
-            // two positions per thread (PH * PWU = 648 <= 2 * 512); every load is issued before the first
-            // LDS store so the tile costs one memory latency
-            float v[2][PC];
-            int pos[2];
+        float stage_v[2][PC];
+        if (c0 == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int i = tid + j * GTHREADS;
-                pos[j] = i < PH * PWU ? i : -1;
-                const int ii = min(i, PH * PWU - 1);
-                const int yy = ii / PWU, xx = ii - yy * PWU;
-                const int cy = min(max(tr0 + yy - 1, 0), H - 1), cx = min(max(tx0 + xx - 1, 0), W - 1);
-                const float* src = pixels + ((size_t)cy * W + cx) * C + c0;
-                if (nch == 4 && (C & 3) == 0 && p.pixels_aligned16) {
-                    const float4 q = *reinterpret_cast<const float4*>(src);  // c0 is a multiple of 4 here
-                    v[j][0] = q.x; v[j][1] = q.y; v[j][2] = q.z; v[j][3] = q.w;
-                } else {
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int ch = 0; ch < PC; ++ch) v[j][ch] = ch < nch ? src[ch] : 0.f;
-                }
-            }
+                for (int ch = 0; ch < PC; ++ch) stage_v[j][ch] = stage0_v[j][ch];  // loaded before phase A
+        } else {
+            stage_load(c0, nch, stage_v);
+        }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (pos[j] < 0) continue;
-                const int yy = pos[j] / PWU, xx = pos[j] - yy * PWU;
+        for (int j = 0; j < 2; ++j) {
+            const int pos = tid + j * GTHREADS;
+            if (pos >= PH * PWU) continue;
+            const int yy = pos / PWU, xx = pos - yy * PWU;
 #pragma unroll
-                for (int ch = 0; ch < PC; ++ch) {
-                    if (ch < nch) {
-                        s_pix[ch][yy][xx] = v[j][ch];
-                        pmax = fmaxf(pmax, fabsf(v[j][ch]));
-                        if (!(v[j][ch] == v[j][ch])) pmax = INFINITY;
-                    }
+            for (int ch = 0; ch < PC; ++ch) {
+                if (ch < nch) {
+                    s_pix[ch][yy][xx] = stage_v[j][ch];
+                    pmax = fmaxf(pmax, fabsf(stage_v[j][ch]));
+                    if (!(stage_v[j][ch] == stage_v[j][ch])) pmax = INFINITY;
                 }
             }
         }
         float gch[PC];
 #pragma unroll
         for (int c = 0; c < PC; ++c) {
-            gch[c] = (c < nch) ? g_here[c0 + c] : 0.f;
+            gch[c] = c0 == 0 ? g0v[c] : ((c < nch) ? g_here[c0 + c] : 0.f);
             gmax = fmaxf(gmax, fabsf(gch[c]));
         }
         // (NaNs do not survive fmaxf: they are folded in explicitly so the inf/NaN fallback sees them)
@@ -399,9 +422,14 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
         // ---- background gradient (:143-147) and colour gradients (:135-142) of the pass's channels ----
         if (inside) {
             float* gbk = p.grad_background + pix * C + c0;
+            if (nch == 4 && (C & 3) == 0 && p.pixels_aligned16) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(gbk) = face_here >= 0 ? z : make_float4(gch[0], gch[1], gch[2], gch[3]);
+            } else {
 #pragma unroll
-            for (int c = 0; c < PC; ++c)
-                if (c < nch) gbk[c] = face_here >= 0 ? 0.f : gch[c];
+                for (int c = 0; c < PC; ++c)
+                    if (c < nch) gbk[c] = face_here >= 0 ? 0.f : gch[c];
+            }
         }
         {
             const float hb[3] = {fh4.x, fh4.y, fh4.z};
@@ -423,6 +451,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
             }
         }
 
+        GMARK();  // colour done
         // ---- channel groups of the pass: Scharr, dilation, position gradients ----
         for (int cg = 0; cg < nch;) {
             const int c_begin = c0 + cg;
@@ -453,6 +482,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                 }
             }
 
+            GMARK();  // scharr
             // dilation, :155-194: which pixel's (barycentric, indices, clip_w) this pixel uses
             int cy_l = py_l, cx_l = px_l;  // position (in the halo'd tile) of the fragment used
             bool dilated = false;
@@ -502,6 +532,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                 }
             }
 
+            GMARK();  // dilation
             // position gradients, :196-232
             const int32_t face_cur = inside ? s_vis[cy_l][cx_l] : -1;
             const bool covered = face_cur >= 0;
@@ -544,6 +575,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                 pv[k * 3 + 1] = quad_reduce(t_cur, covered ? dLy_b * d_yview_by_yclip : 0.f);
                 pv[k * 3 + 2] = quad_reduce(t_cur, covered ? gw1 + gw2 : 0.f);
             }
+            GMARK();  // position math + quad
             if (finite && slot_cur != -2) {
                 fix_add<9>(s_acc, t_cur, 0, pv, fp.to_fix);
             } else if (covered && (t_cur.active || slot_cur == -2)) {
@@ -555,6 +587,7 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                     atomicAdd(gv + 3, pv[k * 3 + 2]);
                 }
             }
+            GMARK();  // fix_add
             cg += G;
         }
         GMARK();  // 5 accumulated
@@ -569,7 +602,9 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
 #pragma unroll
             for (int cp = 0; cp < COPIES; ++cp) { sum += (long long)a[cp]; a[cp] = 0ull; }
             if (sum == 0) continue;
-            const float f = (float)((double)sum * (double)(v < 9 ? fp.from_fix : fc.from_fix));
+            // |sum| < 2^45: two exact conversions and one fma instead of the generic int64 -> double sequence
+            const double dsum = fma((double)(int32_t)(sum >> 32), 4294967296.0, (double)(uint32_t)sum);
+            const float f = (float)(dsum * (double)(v < 9 ? fp.from_fix : fc.from_fix));
             if (v < 9) {
                 const int k = v / 3, comp = v - k * 3;
                 atomicAdd(&grad_vertices[(size_t)s_vid[slot][k] * 4 + (comp == 2 ? 3 : comp)], f);
@@ -601,7 +636,7 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     p.tiles_x = (p.W + GW - 1) / GW;
     p.tiles_y = (p.H + GH - 1) / GH;
     p.nslots = MAX_SLOTS;
-    p.pixels_aligned16 = (reinterpret_cast<uintptr_t>(p.pixels) & 15u) == 0 ? 1 : 0;
+    p.pixels_aligned16 = ((reinterpret_cast<uintptr_t>(p.pixels) | reinterpret_cast<uintptr_t>(p.grad_background)) & 15u) == 0 ? 1 : 0;
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.B);
     hipLaunchKernelGGL(grad_kernel, grid, dim3(GTHREADS), 0, stream, p);
     return hipGetLastError();

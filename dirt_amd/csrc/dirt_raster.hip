@@ -179,7 +179,7 @@ constexpr int LIST_CAP = 2048;    // bin entries scanned (and at most listed) pe
 // wave-uniform address, so it is fetched with scalar loads and lives in SGPRs.
 struct RecCore {
     double coef[9];
-    double zs[3];
+    double zp[3];  // depth plane
     uint32_t flags;
     uint32_t pad;
 };
@@ -187,8 +187,8 @@ static_assert(sizeof(RecCore) == 104, "RecCore is the head of FaceRec");
 
 // Coverage + depth + visibility update of one block (one pixel per lane) for one candidate.
 // F_k = fma(a_k, px, fma(b_k, py, c_k)) exactly as the specification writes it; the inner fma is
-// shared by the two blocks of a block row (`trow`).
-__device__ __forceinline__ void raster_block(const RecCore& rec, int face, double px, const double trow[3],
+// shared by the two blocks of a block row (`trow`), as is that of the depth plane (`zrow`).
+__device__ __forceinline__ void raster_block(const RecCore& rec, int face, double px, const double trow[3], double zrow,
                                              uint32_t& zbest, int32_t& fbest)
 {
     const double F0 = fma(rec.coef[0], px, trow[0]);
@@ -198,8 +198,7 @@ __device__ __forceinline__ void raster_block(const RecCore& rec, int face, doubl
     const bool c1 = (F1 >= 0.0) != ((rec.flags & 2u) != 0);
     const bool c2 = (F2 >= 0.0) != ((rec.flags & 4u) != 0);
     if (c0 && c1 && c2) {
-        const double t = F2 * rec.zs[2];
-        const double zn = fma(F0, rec.zs[0], fma(F1, rec.zs[1], t));
+        const double zn = fma(rec.zp[0], px, zrow);
         if (zn >= -1.0 && zn <= 1.0) {
             const uint32_t z24 = (uint32_t)rint(fma(zn, 8388607.5, 8388607.5));
             // GL_LESS against the stored depth; equal depth keeps the lower face index, which is
@@ -220,9 +219,11 @@ __device__ __forceinline__ void raster_candidate(const RecCore& rec, int face, u
             trow[0] = fma(rec.coef[1], py[by], rec.coef[2]);
             trow[1] = fma(rec.coef[4], py[by], rec.coef[5]);
             trow[2] = fma(rec.coef[7], py[by], rec.coef[8]);
+            const double zrow = fma(rec.zp[1], py[by], rec.zp[2]);
 #pragma unroll
             for (int bx = 0; bx < 2; ++bx)
-                if ((m4 >> (2 * by + bx)) & 1u) raster_block(rec, face, px[bx], trow, zbest[2 * by + bx], fbest[2 * by + bx]);
+                if ((m4 >> (2 * by + bx)) & 1u)
+                    raster_block(rec, face, px[bx], trow, zrow, zbest[2 * by + bx], fbest[2 * by + bx]);
         }
     }
 }

@@ -43,8 +43,10 @@
  *       inside iff for all k: E_k > 0 or (E_k == 0 and (a_k > 0 or (a_k == 0 and b_k > 0)))
  *               -- watertight tie rule: a sample on an edge belongs to the triangle whose
  *                  interior lies at larger x, or for horizontal edges at larger framebuffer row.
- *       zn    = fma(E_0, zs_0, fma(E_1, zs_1, E_2*zs_2))             NDC depth, zs_k = (double)z_k * inv_det
- *                                                                    (set-up time); kept iff -1<=zn<=1
+ *       zn    = fma(zA, px, fma(zB, py, zC))                         NDC depth, kept iff -1<=zn<=1.  NDC depth is
+ *               sum_k E_k*z_k/det, which is affine in (px,py); its plane is fixed at set-up time:
+ *               zs_k = (double)z_k * inv_det ;
+ *               zA = (a_0*zs_0 + a_1*zs_1) + a_2*zs_2 ; zB, zC likewise from b_k, c_k
  *       z24   = (uint32) rint(fma(zn, 8388607.5, 8388607.5))         24-bit depth (D24S8 buffer,
  *                                                                    csrc/rasterise_egl.cpp:245)
  *       the fragment wins iff z24 < stored (GL_LESS, buffer cleared to 0xFFFFFF); faces are
@@ -72,7 +74,7 @@ typedef struct {
     double a[3], b[3], c[3];
     double inv_det;
     double z[3];  /* clip-space z of the three vertices */
-    double zs[3]; /* z[k] * inv_det */
+    double zp[3]; /* depth plane zA, zB, zC: zn = fma(zA, px, fma(zB, py, zC)) */
     int32_t vid[3];
     int incl[3];
     int i_min, i_max, r_min, r_max; /* pixel-column range and tensor-row range, inclusive */
@@ -113,9 +115,16 @@ static void setup_face(const float *verts, int V, const int32_t *face, int H, in
     }
     o->inv_det = 1.0 / det;
     if (!isfinite(o->inv_det)) return;
+    double zs[3];
     for (int k = 0; k < 3; ++k) {
         o->incl[k] = (o->a[k] > 0.0) || (o->a[k] == 0.0 && o->b[k] > 0.0);
-        o->zs[k] = o->z[k] * o->inv_det;
+        zs[k] = o->z[k] * o->inv_det;
+    }
+    {
+        double m0, m1, m2;
+        m0 = o->a[0] * zs[0]; m1 = o->a[1] * zs[1]; m2 = o->a[2] * zs[2]; o->zp[0] = (m0 + m1) + m2;
+        m0 = o->b[0] * zs[0]; m1 = o->b[1] * zs[1]; m2 = o->b[2] * zs[2]; o->zp[1] = (m0 + m1) + m2;
+        m0 = o->c[0] * zs[0]; m1 = o->c[1] * zs[1]; m2 = o->c[2] * zs[2]; o->zp[2] = (m0 + m1) + m2;
     }
 
     /* Conservative screen bounding box (only a work-skipping device: the edge test decides). */
@@ -156,10 +165,9 @@ static inline int sample_inside(const OFace *o, double px, double py, double E[3
     return 1;
 }
 
-static inline int sample_depth(const OFace *o, const double E[3], uint32_t *z24)
+static inline int sample_depth(const OFace *o, double px, double py, uint32_t *z24)
 {
-    double t = E[2] * o->zs[2];
-    double zn = fma(E[0], o->zs[0], fma(E[1], o->zs[1], t));
+    double zn = fma(o->zp[0], px, fma(o->zp[1], py, o->zp[2]));
     if (!(zn >= -1.0 && zn <= 1.0)) return 0;
     *z24 = (uint32_t)rint(fma(zn, 8388607.5, 8388607.5));
     return 1;
@@ -202,7 +210,7 @@ static void scene_visibility(const OFace *faces, int F, int H, int W, int32_t *f
                     double E[3];
                     uint32_t z24;
                     if (!sample_inside(o, (double)i + 0.5, py, E)) continue;
-                    if (!sample_depth(o, E, &z24)) continue;
+                    if (!sample_depth(o, (double)i + 0.5, py, &z24)) continue;
                     uint32_t *zb = &zbuf[(size_t)(r - r0) * W + i];
                     if (z24 < *zb) { *zb = z24; face_id[(size_t)r * W + i] = f; }
                 }
