@@ -26,7 +26,8 @@ _lib = None
 
 # every symbol include/dirt_hip.h declares (tests/test_boundary.py checks header <-> library)
 SYMBOLS = ('dirt_abi_version', 'dirt_last_error', 'dirt_workspace_bytes', 'dirt_rasterise_forward',
-           'dirt_rasterise_backward', 'dirt_rasterise_visibility', 'dirt_profile_count', 'dirt_profile_name',
+           'dirt_rasterise_backward', 'dirt_rasterise_visibility', 'dirt_state_grad_buffers', 'dirt_profile_count',
+           'dirt_profile_name',
            'dirt_profile_read', 'dirt_profile_reset')
 
 
@@ -59,6 +60,8 @@ def load():
     lib.dirt_rasterise_backward.restype = i
     lib.dirt_rasterise_visibility.argtypes = [fp, ip, ip, i, i, i, i, i, vp, sz, u, vp]
     lib.dirt_rasterise_visibility.restype = i
+    lib.dirt_state_grad_buffers.argtypes = [vp, sz, i, i, i, i, i, i, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    lib.dirt_state_grad_buffers.restype = i
     lib.dirt_profile_count.restype = i
     lib.dirt_profile_name.argtypes = [i]
     lib.dirt_profile_name.restype = ctypes.c_char_p

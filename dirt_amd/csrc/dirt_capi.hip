@@ -81,12 +81,12 @@ void drain_profile()
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
-    size_t recs_off, boxes_off, ctrs_off, chunk_off, entries_off, big_off, vis_off, total;
+    size_t recs_off, boxes_off, ctrs_off, chunk_off, entries_off, big_off, vis_off, gv_off, gvc_off, total;
 };
 
 // Layout: [FaceRec x B*F | FaceBox x B*F | BinCounters x B | chunk histograms | BinEntry x B*4F | BinEntry x B*F |
-//          int32 visibility x B*H*W]
-Workspace carve(int B, int F, int H, int W)
+//          int32 visibility x B*H*W | float grad_vertices x B*V*4 | float grad_vertex_colors x B*V*C]
+Workspace carve(int B, int V, int F, int H, int W, int C)
 {
     Workspace w;
     size_t off = 0;
@@ -99,6 +99,9 @@ Workspace carve(int B, int F, int H, int W)
     w.entries_off = off; off = align_up(off + (size_t)B * 4 * F * sizeof(dirt::BinEntry), 256);
     w.big_off = off;     off = align_up(off + (size_t)B * F * sizeof(dirt::BinEntry), 256);
     w.vis_off = off;     off = align_up(off + (size_t)B * H * W * sizeof(int32_t), 256);
+    // gradient accumulators of the backward pass, pre-cleared by a KEEP_STATE forward (dirt_state_grad_buffers)
+    w.gv_off = off;      off = align_up(off + (size_t)B * V * 4 * sizeof(float), 256);
+    w.gvc_off = off;     off = align_up(off + (size_t)B * V * C * sizeof(float), 256);
     w.total = off + 256;
     return w;
 }
@@ -111,6 +114,8 @@ struct Carved {
     dirt::BinEntry* entries;
     dirt::BinEntry* big;
     int32_t* vis;
+    float* gv;
+    float* gvc;
 };
 
 int check_sizes(const char* who, int B, int V, int F, int H, int W, int C)
@@ -168,6 +173,8 @@ Carved carved(void* workspace, const Workspace& w)
     c.entries = reinterpret_cast<dirt::BinEntry*>(ws + w.entries_off);
     c.big = reinterpret_cast<dirt::BinEntry*>(ws + w.big_off);
     c.vis = reinterpret_cast<int32_t*>(ws + w.vis_off);
+    c.gv = reinterpret_cast<float*>(ws + w.gv_off);
+    c.gvc = reinterpret_cast<float*>(ws + w.gvc_off);
     return c;
 }
 
@@ -205,7 +212,7 @@ const char* dirt_last_error(void) { return g_last_error; }
 size_t dirt_workspace_bytes(int B, int V, int F, int H, int W, int C)
 {
     if (check_sizes("dirt_workspace_bytes", B, V, F, H, W, C) != DIRT_OK) return 0;
-    return carve(B, F, H, W).total;
+    return carve(B, V, F, H, W, C).total;
 }
 
 int dirt_rasterise_forward(const float* background, const float* vertices, const float* vertex_colors,
@@ -221,13 +228,17 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
         return fail(DIRT_E_INVALID_ARGUMENT, "%s: vertices / vertex_colors / faces is NULL", who);
     rc = check_aligned(who, {background, vertices, vertex_colors, faces, pixels});
     if (rc) return rc;
-    const Workspace w = carve(B, F, H, W);
+    const Workspace w = carve(B, V, F, H, W, C);
     rc = check_workspace(who, w, workspace, workspace_bytes);
     if (rc) return rc;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const Carved c = carved(workspace, w);
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
-    const dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W);
+    dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W);
+    if (flags & DIRT_FLAG_KEEP_STATE) {  // pre-clear the backward pass's accumulators (dirt_state_grad_buffers)
+        g.zero_b = c.gv;  g.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
+        g.zero_c = c.gvc; g.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
+    }
     {
         Scope sc(prof, SLOT_GEOMETRY, stream);
         HIP_TRY(who, dirt::launch_geometry(g, stream));
@@ -255,7 +266,7 @@ int dirt_rasterise_visibility(const float* vertices, const int32_t* faces, int32
         return fail(DIRT_E_INVALID_ARGUMENT, "%s: vertices / faces is NULL", who);
     rc = check_aligned(who, {vertices, faces, face_id});
     if (rc) return rc;
-    const Workspace w = carve(B, F, H, W);
+    const Workspace w = carve(B, V, F, H, W, 1);
     rc = check_workspace(who, w, workspace, workspace_bytes);
     if (rc) return rc;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -293,7 +304,7 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
         return fail(DIRT_E_INVALID_ARGUMENT, "%s: vertices / faces / grad_vertices / grad_vertex_colors is NULL", who);
     rc = check_aligned(who, {vertices, faces, pixels, grad_pixels, grad_background, grad_vertices, grad_vertex_colors});
     if (rc) return rc;
-    const Workspace w = carve(B, F, H, W);
+    const Workspace w = carve(B, V, F, H, W, C);
     rc = check_workspace(who, w, workspace, workspace_bytes);
     if (rc) return rc;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -303,10 +314,13 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
     // are cleared by one launch; grad_background and debug_thingy are fully written by the gradient
     // kernel instead
     if (flags & DIRT_FLAG_REUSE_STATE) {
-        // records + visibility were left in this workspace by the forward pass
-        Scope sc(prof, SLOT_GEOMETRY, stream);
-        HIP_TRY(who, dirt::launch_zero(grad_vertices, sizeof(float) * (size_t)B * V * 4, grad_vertex_colors,
-                                       sizeof(float) * (size_t)B * V * C, stream));
+        // records + visibility were left in this workspace by the forward pass; so were cleared gradient
+        // accumulators: if the caller's outputs ARE those (dirt_state_grad_buffers) nothing is left to do
+        if (!(grad_vertices == c.gv && grad_vertex_colors == c.gvc)) {
+            Scope sc(prof, SLOT_GEOMETRY, stream);
+            HIP_TRY(who, dirt::launch_zero(grad_vertices, sizeof(float) * (size_t)B * V * 4, grad_vertex_colors,
+                                           sizeof(float) * (size_t)B * V * C, stream));
+        }
     } else {
         dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W);
         g.zero_b = grad_vertices;      g.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
@@ -335,6 +349,21 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
         HIP_TRY(who, dirt::launch_grad(gp, stream));
     }
     g_last_error[0] = 0;
+    return DIRT_OK;
+}
+
+int dirt_state_grad_buffers(void* workspace, size_t workspace_bytes, int B, int V, int F, int H, int W, int C,
+                            float** grad_vertices, float** grad_vertex_colors)
+{
+    const char* who = "dirt_state_grad_buffers";
+    int rc = check_sizes(who, B, V, F, H, W, C);
+    if (rc) return rc;
+    const Workspace w = carve(B, V, F, H, W, C);
+    rc = check_workspace(who, w, workspace, workspace_bytes);
+    if (rc) return rc;
+    const Carved c = carved(workspace, w);
+    if (grad_vertices) *grad_vertices = c.gv;
+    if (grad_vertex_colors) *grad_vertex_colors = c.gvc;
     return DIRT_OK;
 }
 

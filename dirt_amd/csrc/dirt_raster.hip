@@ -66,6 +66,16 @@ __global__ __launch_bounds__(256) void setup_kernel(GeomParams g)
 {
     __shared__ uint32_t s_cnt[MAX_BINS + 1];  // [MAX_BINS] = big faces
     const int ib = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    // side job: clear the gradient accumulators of the backward pass (the cudaMemsetAsync x4 of
+    // csrc/rasterise_grad_egl.cu:244-250) so that no separate launch is needed for it
+    {
+        const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
+        const size_t gtid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid;
+        uint32_t* zb = reinterpret_cast<uint32_t*>(g.zero_b);
+        uint32_t* zc = reinterpret_cast<uint32_t*>(g.zero_c);
+        for (size_t i = gtid; i < g.zero_b_bytes / 4; i += nthreads) zb[i] = 0u;
+        for (size_t i = gtid; i < g.zero_c_bytes / 4; i += nthreads) zc[i] = 0u;
+    }
     s_cnt[tid] = 0;
     if (tid == 0) s_cnt[MAX_BINS] = 0;
     __syncthreads();
@@ -455,15 +465,7 @@ hipError_t launch_zero(void* b, size_t b_bytes, void* c, size_t c_bytes, hipStre
 
 hipError_t launch_geometry(const GeomParams& g, hipStream_t stream)
 {
-    if (g.zero_b_bytes || g.zero_c_bytes) {
-        const size_t nb = g.zero_b_bytes / 4, nc = g.zero_c_bytes / 4;
-        const size_t most = nb > nc ? nb : nc;
-        unsigned grid = (unsigned)((most + 255) / 256);
-        if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<uint32_t*>(g.zero_b), nb,
-                           reinterpret_cast<uint32_t*>(g.zero_c), nc);
-    }
-    if (g.B == 0) return hipGetLastError();
+    if (g.B == 0) return hipSuccess;
     // also with F == 0: fill publishes the (all-zero) directory the raster kernel reads
     const dim3 grid((unsigned)g.nchunk, (unsigned)g.B);
     hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, stream, g);

@@ -13,6 +13,8 @@ Differences from the reference, by design:
     evaluation (dirt/rasterise_ops.py:86-108,132-177), which issues one op per group;
   * the deferred wrappers rasterise visibility once per gradient call instead of once per group.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -135,18 +137,26 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
     vertices, faces, pixels, grad_pixels = (t.contiguous() for t in (vertices, faces, pixels, grad_pixels))
     B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[1]
     grad_background = torch.empty_like(pixels)
-    grad_vertices = torch.empty_like(vertices)
-    grad_vertex_colors = torch.empty((B, V, channels), dtype=torch.float32, device=dev)
     debug = torch.empty((B, height, width, 3), dtype=torch.float32, device=dev) if want_debug else None
     with torch.cuda.device(dev):
         nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, channels)
         if nbytes == 0:
             raise ValueError(_lib.last_error())
         if state is not None:
+            # the gradients accumulate in the buffers the forward pass already cleared inside `state`;
+            # the returned tensors are views of it
             ws = state
             flags |= _lib.FLAG_REUSE_STATE
+            gv_p, gvc_p = ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.check(lib.dirt_state_grad_buffers(ws.data_ptr(), ws.numel(), B, V, F, height, width, channels,
+                                                   ctypes.byref(gv_p), ctypes.byref(gvc_p)))
+            o1, o2 = gv_p.value - ws.data_ptr(), gvc_p.value - ws.data_ptr()
+            grad_vertices = ws[o1:o1 + B * V * 16].view(torch.float32).view(B, V, 4)
+            grad_vertex_colors = ws[o2:o2 + B * V * channels * 4].view(torch.float32).view(B, V, channels)
         else:
             ws = _workspace(dev, nbytes)
+            grad_vertices = torch.empty_like(vertices)
+            grad_vertex_colors = torch.empty((B, V, channels), dtype=torch.float32, device=dev)
         _lib.check(lib.dirt_rasterise_backward(
             vertices.data_ptr(), faces.data_ptr(), pixels.data_ptr(), grad_pixels.data_ptr(),
             grad_background.data_ptr(), grad_vertices.data_ptr(), grad_vertex_colors.data_ptr(),

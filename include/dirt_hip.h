@@ -121,6 +121,16 @@ int dirt_rasterise_visibility(const float *vertices, const int32_t *faces, int32
                               void *stream);
 
 /*
+ * With DIRT_FLAG_KEEP_STATE the forward pass also clears two gradient accumulators inside the workspace
+ * ([B,V,4] and [B,V,C] floats).  This returns their addresses: a backward call with DIRT_FLAG_REUSE_STATE
+ * whose grad_vertices / grad_vertex_colors ARE these pointers accumulates straight into them and needs no
+ * clearing launch (the reference clears its outputs with four cudaMemsetAsync,
+ * csrc/rasterise_grad_egl.cu:244-250).  Any other output pointers work too; they are cleared first.
+ */
+int dirt_state_grad_buffers(void *workspace, size_t workspace_bytes, int B, int V, int F, int H, int W, int C,
+                            float **grad_vertices, float **grad_vertex_colors);
+
+/*
  * Per-kernel timing (host-side state only).  Slots are the library's kernels; dirt_profile_count()
  * returns how many there are, dirt_profile_name(i) their names.  dirt_profile_read waits for the
  * recorded events of calls made with DIRT_FLAG_PROFILE on this thread, adds them to the running
