@@ -58,6 +58,9 @@ constexpr int COPIES = 4;              // accumulator replicas per (slot, value)
 constexpr int MAX_SLOTS = 64;          // slot table capacity (LDS)
 constexpr int PC = 4;                  // channels per pass: whole channel groups that fit in 4 channels
 constexpr int NVAL = 9 + 3 * PC;       // 9 position values (3 vertices x {x,y,w}) + 3 vertices x PC colour values
+#ifndef GRAD_WAVES_PER_SIMD
+#define GRAD_WAVES_PER_SIMD 4
+#endif
 constexpr int FIX_BITS = 29;           // fixed-point contributions: |q| < 2^FIX_BITS given the tile bound
 
 struct Frag {
@@ -229,7 +232,7 @@ __device__ __noinline__ float2 scharr_taps_wrapped(const float* __restrict__ pix
     return make_float2(sx, sy);
 }
 
-__global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
+__global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(GradParams p)
 {
     __shared__ float s_pix[PC][PH][PW];                              // the pass's channels of `pixels`, edge clamped
     __shared__ __align__(16) unsigned long long s_acc[MAX_SLOTS * NVAL * COPIES];  // fixed-point partial sums
@@ -526,9 +529,11 @@ __global__ __launch_bounds__(GTHREADS) void grad_kernel(GradParams p)
                 float* dbg = p.debug_thingy + pix * 3;
                 dbg[0] = dilated ? 1.e-2f : 0.f;
                 for (int ch = 1; ch <= 2; ++ch) {
-                    size_t m = pix * G + ch;
-                    if (m > total_pix * G - 1) m = total_pix * G - 1;
-                    dbg[ch] = p.grad_pixels[(m / G) * C + c_begin + (m % G)];  // element m of the [B,H,W,G] slice
+                    // element (pix*G + ch) of the contiguous [B,H,W,G] slice of grad_pixels, clamped to its end
+                    size_t mp = G == 3 ? pix : pix + ch;      // pixel of that element
+                    int mc = G == 3 ? ch : 0;                 // channel inside the group
+                    if (mp > total_pix - 1) { mp = total_pix - 1; mc = G - 1; }
+                    dbg[ch] = p.grad_pixels[mp * C + c_begin + mc];
                 }
             }
 
