@@ -1,0 +1,121 @@
+"""Full-size runs (BASELINE.json configs K3 and K5) checked through size-independent properties -- the
+oracle needs seconds per scene at these sizes, the properties need none of it:
+
+  * the visibility-only render and the forward render agree (pixels == background exactly where no face
+    is visible; covered pixels differ from the background);
+  * forward is idempotent and batch-consistent (a scene rendered alone == the same scene inside a batch);
+  * translating the scene by whole pixels translates the visibility buffer;
+  * sum_v grad_vertex_colors[v, c] == sum over covered pixels of grad_pixels[., c]   (sum_k b_k = 1);
+  * grad_background == grad_pixels on uncovered pixels and 0 on covered ones (csrc/rasterise_grad_egl.cu:143-147);
+  * grad_vertices[..., 2] == 0 (:228-230); gradients are linear in grad_pixels;
+  * the stateless backward and the state-reusing backward agree.
+"""
+import numpy as np
+import pytest
+import torch
+
+from dirt_amd import scenes
+from dirt_amd import rasterise_ops as ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(s, dev, keys=('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')):
+    return {k: torch.from_numpy(np.ascontiguousarray(s[k]))[None].to(dev) for k in keys}
+
+
+@pytest.mark.parametrize('config', ['K3', 'K5'])
+def test_fullsize_properties(gpu, config):
+    s = scenes.config_scene(config)
+    H, W, C = s['height'], s['width'], s['channels']
+    t = _dev(s, gpu)
+    px, state = ops._op_rasterise(t['background'], t['vertices'], t['vertex_colors'], t['faces'], H, W, C, keep_state=True)
+    vis = ops._op_visibility(t['vertices'], t['faces'], H, W)
+    covered = vis >= 0
+    frac = float(covered.float().mean())
+    assert 0.5 < frac < 0.95, frac                                  # ~85 % coverage, overdraw ~2
+    # forward vs visibility
+    same = (px == t['background']).all(-1)
+    assert bool(same[~covered].all()), 'uncovered pixels must equal the background exactly'
+    assert float(same[covered].float().mean()) < 1e-3
+    # idempotent
+    assert torch.equal(px, ops._op_rasterise(t['background'], t['vertices'], t['vertex_colors'], t['faces'], H, W, C))
+
+    # backward: both variants
+    a = ops._op_rasterise_grad(t['vertices'], t['faces'], px, t['grad_pixels'], H, W, C, state=state)
+    a = [x.clone() if x is not None else None for x in a]
+    b = ops._op_rasterise_grad(t['vertices'], t['faces'], px, t['grad_pixels'], H, W, C)
+    gb, gv, gvc = a[0], a[1], a[2]
+    assert torch.equal(gb, b[0])
+    scale_v = float(b[1].abs().max()); scale_c = float(b[2].abs().max())
+    assert float((gv - b[1]).abs().max()) <= 1e-4 * scale_v
+    assert float((gvc - b[2]).abs().max()) <= 1e-4 * scale_c
+    g = t['grad_pixels']
+    assert torch.equal(gb, torch.where(covered[..., None], torch.zeros_like(g), g))
+    assert bool((gv[..., 2] == 0).all())
+    want = (g.double() * covered[..., None]).sum(dim=(0, 1, 2))
+    got = gvc.double().sum(dim=(0, 1))
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-2 * float(want.abs().max())), (got, want)
+    # linearity in grad_pixels
+    c2 = ops._op_rasterise_grad(t['vertices'], t['faces'], px, 2.0 * g, H, W, C)
+    assert float((c2[1] - 2.0 * b[1]).abs().max()) <= 2e-4 * scale_v
+    assert float((c2[2] - 2.0 * b[2]).abs().max()) <= 2e-4 * scale_c
+
+
+def test_whole_pixel_translation_translates_visibility(gpu):
+    s = scenes.config_scene('K3')
+    H, W = s['height'], s['width']
+    v = torch.from_numpy(s['vertices'])[None].to(gpu)
+    f = torch.from_numpy(s['faces'])[None].to(gpu)
+    vis0 = ops._op_visibility(v, f, H, W)
+    k = 64                                              # pixels; 2k/W is exactly representable
+    v2 = v.clone()
+    v2[..., 0] += (2.0 * k / W) * v[..., 3]            # x_ndc += 2k/W
+    vis1 = ops._op_visibility(v2, f, H, W)
+    a, b = vis0[:, :, :-k], vis1[:, :, k:]
+    # faces partly pushed off screen keep their index; rounding in (x + w) * W/2 may move a handful of edge samples
+    assert float((a != b).float().mean()) < 1e-4
+
+
+def test_batch_of_k3_scenes_matches_single(gpu):
+    b = scenes.batch_scene(10000, 1024, 1024, 4, seeds=[0, 1], r_lo=0.005, r_hi=0.04)
+    t = {k: torch.from_numpy(b[k]).to(gpu) for k in ('background', 'vertices', 'vertex_colors', 'faces')}
+    both = ops._op_rasterise(t['background'], t['vertices'], t['vertex_colors'], t['faces'], 1024, 1024, 4)
+    for i in range(2):
+        one = ops._op_rasterise(t['background'][i:i + 1], t['vertices'][i:i + 1], t['vertex_colors'][i:i + 1],
+                                t['faces'][i:i + 1], 1024, 1024, 4)
+        assert torch.equal(both[i:i + 1], one)
+
+
+def test_deferred_matches_manual_composition(gpu, oracle):
+    """rasterise_deferred (dirt/rasterise_ops.py:180-310): pixels = shader(gbuffer); vertex gradient from filtering
+    the SHADED image (:204-210), attribute/background gradients from the G-buffer with dL/dgbuffer (:231-237)."""
+    s = scenes.rand_scene(200, 48, 64, 5, 17, 0.05, 0.3)
+    bg = torch.from_numpy(s['background']).to(gpu).requires_grad_(True)
+    v = torch.from_numpy(s['vertices']).to(gpu).requires_grad_(True)
+    attrs = torch.from_numpy(s['vertex_colors']).to(gpu).requires_grad_(True)
+    f = torch.from_numpy(s['faces']).to(gpu)
+    light = torch.tensor([0.3, 0.5, 0.8], device=gpu, requires_grad=True)
+
+    def shader(gbuffer, light_):
+        return gbuffer[..., :3] * (gbuffer[..., 3:4] + gbuffer[..., 4:5]) * light_
+
+    px = ops.rasterise_deferred(bg, v, attrs, f, shader, [light])
+    d = torch.from_numpy(np.random.default_rng(0).standard_normal((48, 64, 3)).astype(np.float32)).to(gpu)
+    px.backward(d)
+
+    gbuf = oracle.forward(s['background'][None], s['vertices'][None], s['vertex_colors'][None], s['faces'][None])
+    gt = torch.from_numpy(gbuf[0]).to(gpu).requires_grad_(True)
+    l2 = light.detach().clone().requires_grad_(True)
+    shaded = shader(gt, l2)
+    assert torch.allclose(px, shaded.detach(), atol=1e-6)
+    shaded.backward(d)
+    want_v = oracle.backward(s['vertices'][None], s['faces'][None], shaded.detach().cpu().numpy()[None], d.cpu().numpy()[None])
+    want_a = oracle.backward(s['vertices'][None], s['faces'][None], gbuf, gt.grad.cpu().numpy()[None])
+    def close(got, want, what):
+        scale = max(1.0, float(np.abs(want).max()))
+        assert float(np.abs(got.cpu().numpy() - want).max()) <= 2e-4 * scale, what
+    close(v.grad, want_v['grad_vertices'][0], 'vertices')
+    close(attrs.grad, want_a['grad_vertex_colors'][0], 'attributes')
+    close(bg.grad, want_a['grad_background'][0], 'background')
+    assert torch.allclose(light.grad, l2.grad, rtol=1e-4, atol=1e-4)
