@@ -24,7 +24,7 @@ namespace dirt {
 // compare per edge, xor-ed with the edge's `excl` flag.
 struct alignas(128) FaceRec {
     double coef[9];   //   0: (a,b,c) of edges 0,1,2, sign-folded
-    double zp[3];     //  72: depth plane: zn = fma(zp[0], px, fma(zp[1], py, zp[2]))
+    double zp[3];     //  72: depth plane scaled to the 24-bit range: q = fma(zp[0], px, fma(zp[1], py, zp[2]))
     uint32_t flags;   //  96: bit k = edge k folded (exclusive); bit 31 = valid
     uint32_t pad0;    // 100
     double inv_det;   // 104: 1/|det|
@@ -109,9 +109,9 @@ __device__ inline bool setup_face(const float* __restrict__ verts, int V, const 
     for (int k = 0; k < 3; ++k) zs[k] = Z[k] * inv_det;
     {
         double m0, m1, m2;
-        m0 = a[0] * zs[0]; m1 = a[1] * zs[1]; m2 = a[2] * zs[2]; rec.zp[0] = (m0 + m1) + m2;
-        m0 = b[0] * zs[0]; m1 = b[1] * zs[1]; m2 = b[2] * zs[2]; rec.zp[1] = (m0 + m1) + m2;
-        m0 = c[0] * zs[0]; m1 = c[1] * zs[1]; m2 = c[2] * zs[2]; rec.zp[2] = (m0 + m1) + m2;
+        m0 = a[0] * zs[0]; m1 = a[1] * zs[1]; m2 = a[2] * zs[2]; rec.zp[0] = ((m0 + m1) + m2) * 8388607.5;
+        m0 = b[0] * zs[0]; m1 = b[1] * zs[1]; m2 = b[2] * zs[2]; rec.zp[1] = ((m0 + m1) + m2) * 8388607.5;
+        m0 = c[0] * zs[0]; m1 = c[1] * zs[1]; m2 = c[2] * zs[2]; rec.zp[2] = fma((m0 + m1) + m2, 8388607.5, 8388607.5);
     }
     uint32_t flags = FACE_VALID;
     for (int k = 0; k < 3; ++k) {

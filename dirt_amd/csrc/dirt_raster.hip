@@ -189,7 +189,7 @@ constexpr int LIST_CAP = 2048;    // bin entries scanned (and at most listed) pe
 // wave-uniform address, so it is fetched with scalar loads and lives in SGPRs.
 struct RecCore {
     double coef[9];
-    double zp[3];  // depth plane
+    double zp[3];  // depth plane, scaled to the 24-bit range
     uint32_t flags;
     uint32_t pad;
 };
@@ -208,9 +208,9 @@ __device__ __forceinline__ void raster_block(const RecCore& rec, int face, doubl
     const bool c1 = (F1 >= 0.0) != ((rec.flags & 2u) != 0);
     const bool c2 = (F2 >= 0.0) != ((rec.flags & 4u) != 0);
     if (c0 && c1 && c2) {
-        const double zn = fma(rec.zp[0], px, zrow);
-        if (zn >= -1.0 && zn <= 1.0) {
-            const uint32_t z24 = (uint32_t)rint(fma(zn, 8388607.5, 8388607.5));
+        const double q = fma(rec.zp[0], px, zrow);  // depth scaled to [0, 2^24-1]; kept iff inside (the depth clip)
+        if (q >= 0.0 && q <= 16777215.0) {
+            const uint32_t z24 = (uint32_t)rint(q);
             // GL_LESS against the stored depth; equal depth keeps the lower face index, which is
             // what drawing the faces in index order does (csrc/rasterise_egl.cpp:373-379).
             if (z24 < zbest || (z24 == zbest && face < fbest)) { zbest = z24; fbest = face; }

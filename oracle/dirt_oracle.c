@@ -43,11 +43,14 @@
  *       inside iff for all k: E_k > 0 or (E_k == 0 and (a_k > 0 or (a_k == 0 and b_k > 0)))
  *               -- watertight tie rule: a sample on an edge belongs to the triangle whose
  *                  interior lies at larger x, or for horizontal edges at larger framebuffer row.
- *       zn    = fma(zA, px, fma(zB, py, zC))                         NDC depth, kept iff -1<=zn<=1.  NDC depth is
- *               sum_k E_k*z_k/det, which is affine in (px,py); its plane is fixed at set-up time:
+ *       q     = fma(qA, px, fma(qB, py, qC))                         window depth scaled to the 24-bit range:
+ *               NDC depth zn = sum_k E_k*z_k/det is affine in (px,py); q = zn*S + S with S = 8388607.5
+ *               = (2^24-1)/2 maps [-1,1] to [0, 2^24-1].  The plane is fixed at set-up time:
  *               zs_k = (double)z_k * inv_det ;
- *               zA = (a_0*zs_0 + a_1*zs_1) + a_2*zs_2 ; zB, zC likewise from b_k, c_k
- *       z24   = (uint32) rint(fma(zn, 8388607.5, 8388607.5))         24-bit depth (D24S8 buffer,
+ *               zA = (a_0*zs_0 + a_1*zs_1) + a_2*zs_2 ; zB, zC likewise from b_k, c_k ;
+ *               qA = zA*S ; qB = zB*S ; qC = fma(zC, S, S)
+ *               the fragment is kept iff 0 <= q <= 16777215 (the depth clip -1<=zn<=1)
+ *       z24   = (uint32) rint(q)                                     24-bit depth (D24S8 buffer,
  *                                                                    csrc/rasterise_egl.cpp:245)
  *       the fragment wins iff z24 < stored (GL_LESS, buffer cleared to 0xFFFFFF); faces are
  *       visited in index order so the earlier face wins ties.
@@ -74,7 +77,7 @@ typedef struct {
     double a[3], b[3], c[3];
     double inv_det;
     double z[3];  /* clip-space z of the three vertices */
-    double zp[3]; /* depth plane zA, zB, zC: zn = fma(zA, px, fma(zB, py, zC)) */
+    double zp[3]; /* scaled depth plane qA, qB, qC: q = fma(qA, px, fma(qB, py, qC)) */
     int32_t vid[3];
     int incl[3];
     int i_min, i_max, r_min, r_max; /* pixel-column range and tensor-row range, inclusive */
@@ -122,9 +125,9 @@ static void setup_face(const float *verts, int V, const int32_t *face, int H, in
     }
     {
         double m0, m1, m2;
-        m0 = o->a[0] * zs[0]; m1 = o->a[1] * zs[1]; m2 = o->a[2] * zs[2]; o->zp[0] = (m0 + m1) + m2;
-        m0 = o->b[0] * zs[0]; m1 = o->b[1] * zs[1]; m2 = o->b[2] * zs[2]; o->zp[1] = (m0 + m1) + m2;
-        m0 = o->c[0] * zs[0]; m1 = o->c[1] * zs[1]; m2 = o->c[2] * zs[2]; o->zp[2] = (m0 + m1) + m2;
+        m0 = o->a[0] * zs[0]; m1 = o->a[1] * zs[1]; m2 = o->a[2] * zs[2]; o->zp[0] = ((m0 + m1) + m2) * 8388607.5;
+        m0 = o->b[0] * zs[0]; m1 = o->b[1] * zs[1]; m2 = o->b[2] * zs[2]; o->zp[1] = ((m0 + m1) + m2) * 8388607.5;
+        m0 = o->c[0] * zs[0]; m1 = o->c[1] * zs[1]; m2 = o->c[2] * zs[2]; o->zp[2] = fma((m0 + m1) + m2, 8388607.5, 8388607.5);
     }
 
     /* Conservative screen bounding box (only a work-skipping device: the edge test decides). */
@@ -167,9 +170,9 @@ static inline int sample_inside(const OFace *o, double px, double py, double E[3
 
 static inline int sample_depth(const OFace *o, double px, double py, uint32_t *z24)
 {
-    double zn = fma(o->zp[0], px, fma(o->zp[1], py, o->zp[2]));
-    if (!(zn >= -1.0 && zn <= 1.0)) return 0;
-    *z24 = (uint32_t)rint(fma(zn, 8388607.5, 8388607.5));
+    double q = fma(o->zp[0], px, fma(o->zp[1], py, o->zp[2]));
+    if (!(q >= 0.0 && q <= 16777215.0)) return 0;
+    *z24 = (uint32_t)rint(q);
     return 1;
 }
 
