@@ -45,7 +45,7 @@ def kernel_algorithmic_bytes(P, V, F, C):
     of its own (its output is an intermediate); grad reads pixels, grad_pixels, vertices and writes
     the three gradients."""
     return {
-        'geometry (setup+fill)': 12 * F + 16 * V,
+        'setup_kernel': 12 * F + 16 * V,
         'raster_kernel<shade>': 8 * P * C + 4 * V * C,
         'raster_kernel<visibility>': 0,
         'grad_kernel': 12 * P * C + 16 * V + 16 * V + 4 * V * C,

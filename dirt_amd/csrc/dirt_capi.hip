@@ -25,7 +25,7 @@ int fail(int code, const char* fmt, ...)
 
 // ---- optional per-kernel HIP-event timing (DIRT_FLAG_PROFILE) ----------------------------------
 enum Slot { SLOT_GEOMETRY = 0, SLOT_RASTER_FWD, SLOT_RASTER_VIS, SLOT_GRAD, SLOT_COUNT };
-const char* const kSlotNames[SLOT_COUNT] = {"geometry (setup+fill)", "raster_kernel<shade>",
+const char* const kSlotNames[SLOT_COUNT] = {"setup_kernel", "raster_kernel<shade>",
                                             "raster_kernel<visibility>", "grad_kernel"};
 struct Pending {
     hipEvent_t a, b;
@@ -81,10 +81,10 @@ void drain_profile()
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
-    size_t recs_off, boxes_off, ctrs_off, chunk_off, entries_off, big_off, vis_off, gv_off, gvc_off, total;
+    size_t recs_off, boxes_off, cells_off, entries_off, vis_off, gv_off, gvc_off, total;
 };
 
-// Layout: [FaceRec x B*F | FaceBox x B*F | BinCounters x B | chunk histograms | BinEntry x B*4F | BinEntry x B*F |
+// Layout: [FaceRec x B*F | FaceBox x B*F | chunk x bin directory | per-chunk BinEntry segments (5 per face) |
 //          int32 visibility x B*H*W | float grad_vertices x B*V*4 | float grad_vertex_colors x B*V*C]
 Workspace carve(int B, int V, int F, int H, int W, int C)
 {
@@ -92,12 +92,10 @@ Workspace carve(int B, int V, int F, int H, int W, int C)
     size_t off = 0;
     w.recs_off = off;    off = align_up(off + (size_t)B * F * sizeof(dirt::FaceRec), 256);
     w.boxes_off = off;   off = align_up(off + (size_t)B * F * sizeof(dirt::FaceBox), 256);
-    w.ctrs_off = off;    off = align_up(off + (size_t)B * sizeof(dirt::BinCounters), 256);
     int nchunk, chunk_faces;
     dirt::chunking(F, nchunk, chunk_faces);
-    w.chunk_off = off;   off = align_up(off + (size_t)B * nchunk * (dirt::MAX_BINS + 1) * sizeof(uint32_t), 256);
-    w.entries_off = off; off = align_up(off + (size_t)B * 4 * F * sizeof(dirt::BinEntry), 256);
-    w.big_off = off;     off = align_up(off + (size_t)B * F * sizeof(dirt::BinEntry), 256);
+    w.cells_off = off;   off = align_up(off + (size_t)B * nchunk * (dirt::MAX_BINS + 1) * sizeof(dirt::BinCell), 256);
+    w.entries_off = off; off = align_up(off + (size_t)B * nchunk * 5 * (size_t)chunk_faces * sizeof(dirt::BinEntry), 256);
     w.vis_off = off;     off = align_up(off + (size_t)B * H * W * sizeof(int32_t), 256);
     // gradient accumulators of the backward pass, pre-cleared by a KEEP_STATE forward (dirt_state_grad_buffers)
     w.gv_off = off;      off = align_up(off + (size_t)B * V * 4 * sizeof(float), 256);
@@ -109,10 +107,8 @@ Workspace carve(int B, int V, int F, int H, int W, int C)
 struct Carved {
     dirt::FaceRec* recs;
     dirt::FaceBox* boxes;
-    dirt::BinCounters* ctrs;
-    uint32_t* chunk_count;
+    dirt::BinCell* cells;
     dirt::BinEntry* entries;
-    dirt::BinEntry* big;
     int32_t* vis;
     float* gv;
     float* gvc;
@@ -168,10 +164,8 @@ Carved carved(void* workspace, const Workspace& w)
     Carved c;
     c.recs = reinterpret_cast<dirt::FaceRec*>(ws + w.recs_off);
     c.boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
-    c.ctrs = reinterpret_cast<dirt::BinCounters*>(ws + w.ctrs_off);
-    c.chunk_count = reinterpret_cast<uint32_t*>(ws + w.chunk_off);
+    c.cells = reinterpret_cast<dirt::BinCell*>(ws + w.cells_off);
     c.entries = reinterpret_cast<dirt::BinEntry*>(ws + w.entries_off);
-    c.big = reinterpret_cast<dirt::BinEntry*>(ws + w.big_off);
     c.vis = reinterpret_cast<int32_t*>(ws + w.vis_off);
     c.gv = reinterpret_cast<float*>(ws + w.gv_off);
     c.gvc = reinterpret_cast<float*>(ws + w.gvc_off);
@@ -182,8 +176,8 @@ dirt::GeomParams geom_params(const Carved& c, const float* vertices, const int32
                              int W)
 {
     dirt::GeomParams g;
-    g.vertices = vertices; g.faces = faces; g.recs = c.recs; g.boxes = c.boxes; g.ctrs = c.ctrs;
-    g.chunk_count = c.chunk_count; g.entries = c.entries; g.big = c.big;
+    g.vertices = vertices; g.faces = faces; g.recs = c.recs; g.boxes = c.boxes; g.cells = c.cells;
+    g.entries = c.entries;
     dirt::chunking(F, g.nchunk, g.chunk_faces);
     g.zero_b = nullptr; g.zero_b_bytes = 0; g.zero_c = nullptr; g.zero_c_bytes = 0;
     g.B = B; g.V = V; g.F = F; g.H = H; g.W = W;
@@ -194,7 +188,7 @@ dirt::GeomParams geom_params(const Carved& c, const float* vertices, const int32
 dirt::RasterParams raster_params(const Carved& c, const dirt::GeomParams& g, int C)
 {
     dirt::RasterParams p;
-    p.recs = c.recs; p.ctrs = c.ctrs; p.entries = c.entries; p.big = c.big;
+    p.recs = c.recs; p.cells = c.cells; p.entries = c.entries; p.nchunk = g.nchunk; p.chunk_faces = g.chunk_faces;
     p.background = nullptr; p.vertex_colors = nullptr; p.pixels = nullptr; p.vis = nullptr;
     p.V = g.V; p.F = g.F; p.H = g.H; p.W = g.W; p.C = C;
     p.grid = g.grid; p.tiles_x = 0; p.tiles_y = 0;

@@ -21,12 +21,11 @@ struct alignas(16) BinEntry {
 };
 static_assert(sizeof(BinEntry) == 16, "BinEntry must be 16 bytes");
 
-// Per-scene bin directory, written by fill_kernel (chunk 0) for the raster kernel.
-struct alignas(16) BinCounters {
-    uint32_t count[MAX_BINS];   // faces per bin
-    uint32_t start[MAX_BINS];   // first entry of the bin's segment (exclusive prefix of count)
-    uint32_t big_count;         // faces touching more than 4 bins
-    uint32_t pad[3];
+// One cell of the per-scene chunk x bin directory written by setup_kernel: where, inside chunk c's entry
+// segment, the entries of bin b start, and how many there are.  Column MAX_BINS is the "big" pseudo-bin
+// (faces touching more than 4 bins), which every tile reads.
+struct BinCell {
+    uint32_t start, count;
 };
 
 struct GeomParams {
@@ -34,10 +33,8 @@ struct GeomParams {
     const int32_t* faces;   // [B,F,3]
     FaceRec* recs;          // [B*F]
     FaceBox* boxes;         // [B*F]
-    BinCounters* ctrs;      // [B]
-    uint32_t* chunk_count;  // [B][nchunk][MAX_BINS + 1] per-chunk bin histogram (+ big faces)
-    BinEntry* entries;      // [B][4F]
-    BinEntry* big;          // [B][F]
+    BinCell* cells;         // [B][nchunk][MAX_BINS + 1] chunk x bin directory
+    BinEntry* entries;      // [B][nchunk][5 * chunk_faces] per-chunk entry segments, sorted by bin
     void* zero_b;           // optional extra buffers cleared by the same launch (multiples of 16 bytes)
     size_t zero_b_bytes;
     void* zero_c;
@@ -49,9 +46,9 @@ struct GeomParams {
 
 struct RasterParams {
     const FaceRec* recs;         // [B*F] set-up records (workspace)
-    const BinCounters* ctrs;     // [B]
-    const BinEntry* entries;     // [B][4F] per-bin face lists
-    const BinEntry* big;         // [B][F] faces touching many bins
+    const BinCell* cells;        // [B][nchunk][MAX_BINS + 1] chunk x bin directory
+    const BinEntry* entries;     // [B][nchunk][5 * chunk_faces] per-chunk entry segments, sorted by bin
+    int nchunk, chunk_faces;
     const float* background;     // [B,H,W,C]
     const float* vertex_colors;  // [B,V,C]
     float* pixels;               // [B,H,W,C]

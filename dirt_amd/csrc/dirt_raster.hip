@@ -32,20 +32,18 @@ __device__ long long* g_trace_buf = nullptr;
 #endif
 
 // ---- binning ---------------------------------------------------------------------------------
-// The frame is cut into at most MAX_BINS square bins of 2^shift pixels (>= 128, so a raster tile
-// never straddles two bins).  Two kernels build, per scene, an exact-size list of the faces touching
-// each bin -- the replacement for the GL driver's own binning hardware -- without a single global
-// atomic and without any buffer that needs clearing:
-//   setup_kernel : the scene's faces are cut into `nchunk` contiguous chunks, one 256-thread
-//                  workgroup each.  Per face: set-up record, bounding box, and an LDS count in every
-//                  bin the box touches (faces touching more than 4 bins are counted for the scene's
-//                  "big" list, which every tile reads, so the bin lists hold <= 4F entries in total).
-//                  The chunk's histogram row is stored to chunk_count[chunk][bin].
-//   fill_kernel  : same chunks.  Column sums of the count matrix give each bin's size, an exclusive
-//                  prefix over bins gives its segment, the partial column sum over earlier chunks
-//                  gives this chunk's offset inside the segment; faces then claim slots with LDS
-//                  cursors.  Chunk 0 publishes count / start / big_count for the raster kernel.
-// List order inside a chunk is whatever the LDS atomics produce; visibility does not depend on it.
+// The frame is cut into at most MAX_BINS square bins of 2^shift pixels (>= 128, so a raster tile never
+// straddles two bins).  ONE kernel builds, per scene, exact-size lists of the faces touching each bin -- the
+// replacement for the GL driver's own binning hardware -- without a single global atomic, without any
+// buffer that needs clearing and without any cross-workgroup dependency:
+//   setup_kernel : the scene's faces are cut into `nchunk` contiguous chunks, one 256-thread workgroup
+//                  each.  Pass 1, per face: set-up record, bounding box, and an LDS count in every bin the
+//                  box touches (faces touching more than 4 bins count for the "big" pseudo-bin, which every
+//                  tile reads, so a chunk produces at most 5 * chunk_faces entries).  An LDS prefix over the
+//                  bins turns the counts into the chunk's own bin-sorted segment layout, stored as one row
+//                  of the chunk x bin directory.  Pass 2: the faces claim their slots with LDS cursors.
+// A raster tile then reads column `bin` of the directory (one cell per chunk) and walks those segments.
+// Entry order inside a (chunk, bin) run is whatever the LDS atomics produce; visibility does not depend on it.
 
 __device__ __forceinline__ bool bin_range(const FaceBox& box, const BinGrid& grid, int& bx0, int& bx1, int& by0, int& by1)
 {
@@ -64,8 +62,10 @@ __global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ b, siz
 
 __global__ __launch_bounds__(256) void setup_kernel(GeomParams g)
 {
-    __shared__ uint32_t s_cnt[MAX_BINS + 1];  // [MAX_BINS] = big faces
-    const int ib = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    __shared__ uint32_t s_cnt[MAX_BINS + 1];    // [MAX_BINS] = big faces
+    __shared__ uint32_t s_start[MAX_BINS + 1];  // exclusive prefix of s_cnt = the chunk's segment layout
+    __shared__ uint32_t s_wave[4];
+    const int ib = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // side job: clear the gradient accumulators of the backward pass (the cudaMemsetAsync x4 of
     // csrc/rasterise_grad_egl.cu:244-250) so that no separate launch is needed for it
     {
@@ -81,6 +81,10 @@ __global__ __launch_bounds__(256) void setup_kernel(GeomParams g)
     __syncthreads();
     const int f0 = chunk * g.chunk_faces, f1 = min(g.F, f0 + g.chunk_faces);
     const float* __restrict__ verts = g.vertices + (size_t)ib * g.V * 4;
+
+    // ---- pass 1: set-up + histogram ----
+    FaceBox first_box;  // the box of this thread's first face stays in registers for pass 2
+    first_box.i_min = 32767; first_box.i_max = -32768; first_box.r_min = 32767; first_box.r_max = -32768;
     for (int f = f0 + tid; f < f1; f += 256) {
         const size_t n = (size_t)ib * g.F + f;
         FaceRec rec;
@@ -98,73 +102,41 @@ __global__ __launch_bounds__(256) void setup_kernel(GeomParams g)
             g.recs[n].flags = 0;
             box.i_min = 32767; box.i_max = -32768; box.r_min = 32767; box.r_max = -32768;
         }
-        g.boxes[n] = box;
+        if (f == f0 + tid) first_box = box;
+        if (g.chunk_faces > 256) g.boxes[n] = box;  // re-read in pass 2 when a thread owns several faces
     }
     __syncthreads();
-    uint32_t* __restrict__ row = g.chunk_count + ((size_t)ib * g.nchunk + chunk) * (MAX_BINS + 1);
-    row[tid] = s_cnt[tid];
-    if (tid == 0) row[MAX_BINS] = s_cnt[MAX_BINS];
-}
 
-__global__ __launch_bounds__(256) void fill_kernel(GeomParams g)
-{
-    __shared__ uint32_t s_base[MAX_BINS + 1];  // first slot of this chunk in each bin's segment ([MAX_BINS]: big list)
-    __shared__ uint32_t s_cur[MAX_BINS + 1];
-    __shared__ uint32_t s_wave[4];
-    const int ib = blockIdx.y, chunk = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t* __restrict__ mat = g.chunk_count + (size_t)ib * g.nchunk * (MAX_BINS + 1);
-
-    // column sums over all chunks (bin sizes) and over the chunks before this one
-    uint32_t total = 0, before = 0;
-#pragma unroll 8
-    for (int c = 0; c < g.nchunk; ++c) {
-        const uint32_t v = mat[(size_t)c * (MAX_BINS + 1) + tid];
-        total += v;
-        before += (c < chunk) ? v : 0u;
-    }
-    uint32_t incl = total;  // exclusive prefix of the bin sizes
+    // ---- the chunk's segment layout: exclusive prefix over the 257 (pseudo-)bins ----
+    const uint32_t cnt = s_cnt[tid];
+    uint32_t incl = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t t = __shfl_up(incl, d);
         if (lane >= d) incl += t;
     }
     if (lane == 63) s_wave[wave] = incl;
-    // the big-list column, summed by wave 3 (its lanes stride over the chunks)
-    uint32_t btotal = 0, bbefore = 0;
-    if (wave == 3) {
-        for (int c = lane; c < g.nchunk; c += 64) {
-            const uint32_t v = mat[(size_t)c * (MAX_BINS + 1) + MAX_BINS];
-            btotal += v;
-            bbefore += (c < chunk) ? v : 0u;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            btotal += __shfl_xor(btotal, d);
-            bbefore += __shfl_xor(bbefore, d);
-        }
-    }
     __syncthreads();
     uint32_t off = 0;
     for (int w = 0; w < wave; ++w) off += s_wave[w];
-    const uint32_t start = off + incl - total;
-    s_base[tid] = start + before;
-    s_cur[tid] = 0;
-    BinCounters* __restrict__ ctr = g.ctrs + ib;
-    if (chunk == 0) { ctr->count[tid] = total; ctr->start[tid] = start; }
-    if (tid == 192) {  // lane 0 of wave 3
-        s_base[MAX_BINS] = bbefore;
-        s_cur[MAX_BINS] = 0;
-        if (chunk == 0) ctr->big_count = btotal;
+    const uint32_t start = off + incl - cnt;
+    BinCell* __restrict__ row = g.cells + ((size_t)ib * g.nchunk + chunk) * (MAX_BINS + 1);
+    s_start[tid] = start;
+    row[tid] = BinCell{start, cnt};
+    if (tid == 255) {
+        s_start[MAX_BINS] = start + cnt;
+        row[MAX_BINS] = BinCell{start + cnt, s_cnt[MAX_BINS]};
     }
     __syncthreads();
+    s_cnt[tid] = 0;  // reused as the fill cursors
+    if (tid == 0) s_cnt[MAX_BINS] = 0;
+    __syncthreads();
 
-    const int f0 = chunk * g.chunk_faces, f1 = min(g.F, f0 + g.chunk_faces);
-    BinEntry* __restrict__ out = g.entries + (size_t)ib * 4 * g.F;
-    BinEntry* __restrict__ big = g.big + (size_t)ib * g.F;
+    // ---- pass 2: faces claim their slots in the chunk's segment ----
+    BinEntry* __restrict__ out = g.entries + ((size_t)ib * g.nchunk + chunk) * (5 * (size_t)g.chunk_faces);
     for (int f = f0 + tid; f < f1; f += 256) {
         BinEntry e;
-        e.box = g.boxes[(size_t)ib * g.F + f];
+        e.box = (f == f0 + tid) ? first_box : g.boxes[(size_t)ib * g.F + f];
         if (e.box.i_min > e.box.i_max) continue;  // culled at set-up
         e.face = f; e.pad = 0;
         int bx0, bx1, by0, by1;
@@ -172,10 +144,10 @@ __global__ __launch_bounds__(256) void fill_kernel(GeomParams g)
             for (int by = by0; by <= by1; ++by)
                 for (int bx = bx0; bx <= bx1; ++bx) {
                     const int b = by * g.grid.bins_x + bx;
-                    out[s_base[b] + atomicAdd(&s_cur[b], 1u)] = e;
+                    out[s_start[b] + atomicAdd(&s_cnt[b], 1u)] = e;
                 }
         } else {
-            big[s_base[MAX_BINS] + atomicAdd(&s_cur[MAX_BINS], 1u)] = e;
+            out[s_start[MAX_BINS] + atomicAdd(&s_cnt[MAX_BINS], 1u)] = e;
         }
     }
 }
@@ -185,55 +157,99 @@ constexpr int TILE_H = 32;
 constexpr int RTHREADS = 256;     // 4 waves; each owns a 16 x 16 region = 2 x 2 blocks, 4 pixels per lane
 constexpr int LIST_CAP = 2048;    // bin entries scanned (and at most listed) per round
 
-// The part of a FaceRec the coverage / depth loop needs (its first 104 bytes).  Loaded through a
-// wave-uniform address, so it is fetched with scalar loads and lives in SGPRs.
-struct RecCore {
-    double coef[9];
-    double zp[3];  // depth plane, scaled to the 24-bit range
-    uint32_t flags;
-    uint32_t pad;
+// What the coverage / depth loop reads per candidate: built once per (tile, candidate) by one lane when the
+// candidate is staged in LDS, 80 bytes = five 16-byte LDS reads.
+//
+// The specification decides coverage by the SIGN of E_k = fma(a_k, px, fma(b_k, py, c_k)) in f64 (and a tie
+// rule on exact zeros).  Here E_k is first evaluated in float32 in tile-local coordinates (dx = px - ox in
+// 0..31, dy = py - oy in -31..0, c' = E_k(ox, oy) rounded from f64) together with a certified bound on
+// |E32_k - E_k| over the tile:
+//   |E32 - E| <= u32*(2*31|a| + 3*31|b| + 3|c'|) + 2^-51*Mg,  u32 = 2^-24,  Mg = |a|W + |b|H + |c|
+//            <= 2^-22*(32|a32| + 32|b32| + |c32|) + 2^-49*Mg32 = bnd        (Mg32: Mg from the rounded values)
+// E32_k > bnd_k for every k: certainly inside; some E32_k < -bnd_k: certainly outside; anything else (a
+// ~1e-5 pixel strip along an edge, or exactly on it) takes the specification's f64 path, covered_exact().
+// Results are bit-identical to the specification at a fraction of the f64 work.
+struct alignas(16) TileRec {
+    float a[3], b[3], c[3], bnd[3];  //  0: tile-local float32 edge functions (true sign: inside = positive), bounds
+    double zp[3];                    // 48: depth plane scaled to the 24-bit range, global coordinates
+    uint32_t flags;                  // 72
+    int32_t face;                    // 76
 };
-static_assert(sizeof(RecCore) == 104, "RecCore is the head of FaceRec");
+static_assert(sizeof(TileRec) == 80, "TileRec is 80 bytes");
+
+// One lane builds the TileRec of one candidate.  ox, oy: sample position of the tile's top-left pixel.
+__device__ __forceinline__ void make_tile_rec(const FaceRec* __restrict__ rec, int face, double ox, double oy, float wf, float hf,
+                                              TileRec* out)
+{
+    const uint32_t flags = rec->flags;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double a = rec->coef[3 * k], b = rec->coef[3 * k + 1], c = rec->coef[3 * k + 2];
+        const double cl = fma(a, ox, fma(b, oy, c));
+        const float sg = (flags & (1u << k)) ? -1.f : 1.f;  // undo the sign folding: E_k = sg * F_k
+        const float a32 = (float)a, b32 = (float)b, c32 = (float)cl, cg = (float)c;
+        const float mg = fabsf(a32) * wf + fabsf(b32) * hf + fabsf(cg);
+        out->bnd[k] = (0x1p-22f * (32.f * fabsf(a32) + 32.f * fabsf(b32) + fabsf(c32)) + 0x1p-49f * mg) * 1.0001f;
+        out->a[k] = sg * a32; out->b[k] = sg * b32; out->c[k] = sg * c32;
+    }
+    out->zp[0] = rec->zp[0]; out->zp[1] = rec->zp[1]; out->zp[2] = rec->zp[2];
+    out->flags = flags; out->face = face;
+}
+
+// The specification's f64 coverage test for the samples the float filter cannot decide.  Rare; kept out of
+// line (and reading the FaceRec from global memory) so that nothing of it is speculated into the main loop.
+__device__ __noinline__ bool covered_exact(const FaceRec* __restrict__ rec, double px, double py)
+{
+    const uint32_t flags = rec->flags;
+    const double F0 = fma(rec->coef[0], px, fma(rec->coef[1], py, rec->coef[2]));
+    const double F1 = fma(rec->coef[3], px, fma(rec->coef[4], py, rec->coef[5]));
+    const double F2 = fma(rec->coef[6], px, fma(rec->coef[7], py, rec->coef[8]));
+    return ((F0 >= 0.0) != ((flags & 1u) != 0)) && ((F1 >= 0.0) != ((flags & 2u) != 0)) && ((F2 >= 0.0) != ((flags & 4u) != 0));
+}
 
 // Coverage + depth + visibility update of one block (one pixel per lane) for one candidate.
-// F_k = fma(a_k, px, fma(b_k, py, c_k)) exactly as the specification writes it; the inner fma is
-// shared by the two blocks of a block row (`trow`), as is that of the depth plane (`zrow`).
-__device__ __forceinline__ void raster_block(const RecCore& rec, int face, double px, const double trow[3], double zrow,
-                                             uint32_t& zbest, int32_t& fbest)
+// dx: this lane's tile-local column; trow[k] = fmaf(b_k, dy, c_k) of the block row; px, py the sample
+// position; qrow = fma(zp[1], py, zp[2]) of the block row.
+__device__ __forceinline__ void raster_block(const TileRec& t, const FaceRec* __restrict__ recs, float dx, const float trow[3],
+                                             double px, double py, double qrow, uint32_t& zbest, int32_t& fbest)
 {
-    const double F0 = fma(rec.coef[0], px, trow[0]);
-    const double F1 = fma(rec.coef[3], px, trow[1]);
-    const double F2 = fma(rec.coef[6], px, trow[2]);
-    const bool c0 = (F0 >= 0.0) != ((rec.flags & 1u) != 0);
-    const bool c1 = (F1 >= 0.0) != ((rec.flags & 2u) != 0);
-    const bool c2 = (F2 >= 0.0) != ((rec.flags & 4u) != 0);
-    if (c0 && c1 && c2) {
-        const double q = fma(rec.zp[0], px, zrow);  // depth scaled to [0, 2^24-1]; kept iff inside (the depth clip)
-        if (q >= 0.0 && q <= 16777215.0) {
-            const uint32_t z24 = (uint32_t)rint(q);
-            // GL_LESS against the stored depth; equal depth keeps the lower face index, which is
-            // what drawing the faces in index order does (csrc/rasterise_egl.cpp:373-379).
-            if (z24 < zbest || (z24 == zbest && face < fbest)) { zbest = z24; fbest = face; }
-        }
+    const float E0 = fmaf(t.a[0], dx, trow[0]);
+    const float E1 = fmaf(t.a[1], dx, trow[1]);
+    const float E2 = fmaf(t.a[2], dx, trow[2]);
+    const float lo = fminf(fminf(E0 - t.bnd[0], E1 - t.bnd[1]), E2 - t.bnd[2]);
+    const float hi = fminf(fminf(E0 + t.bnd[0], E1 + t.bnd[1]), E2 + t.bnd[2]);
+    bool cov = lo > 0.f;                             // certainly inside
+    const bool unsure = !(lo > 0.f) && !(hi < 0.f);  // neither certainly inside nor outside (NaN lands here)
+    if (__builtin_expect(__ballot(unsure) != 0ull, 0)) {
+        if (unsure) cov = covered_exact(recs + t.face, px, py);
     }
+    if (__ballot(cov) == 0ull) return;
+    const double q = fma(t.zp[0], px, qrow);  // depth scaled to [0, 2^24-1]; kept iff inside (the depth clip)
+    const uint32_t z24 = (uint32_t)rint(q);
+    // GL_LESS against the stored depth; equal depth keeps the lower face index, which is what drawing the
+    // faces in index order does (csrc/rasterise_egl.cpp:373-379)
+    const bool wins = cov && q >= 0.0 && q <= 16777215.0 && (z24 < zbest || (z24 == zbest && t.face < fbest));
+    zbest = wins ? z24 : zbest;
+    fbest = wins ? t.face : fbest;
 }
 
 // One candidate against the wave's 2 x 2 blocks; `m4` (wave-uniform) says which blocks its box touches.
-__device__ __forceinline__ void raster_candidate(const RecCore& rec, int face, uint32_t m4, const double px[2],
-                                                 const double py[2], uint32_t zbest[4], int32_t fbest[4])
+__device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec* __restrict__ recs, uint32_t m4, const float dx[2],
+                                                 const float dy[2], const double px[2], const double py[2], uint32_t zbest[4],
+                                                 int32_t fbest[4])
 {
 #pragma unroll
     for (int by = 0; by < 2; ++by) {
         if ((m4 >> (2 * by)) & 3u) {
-            double trow[3];
-            trow[0] = fma(rec.coef[1], py[by], rec.coef[2]);
-            trow[1] = fma(rec.coef[4], py[by], rec.coef[5]);
-            trow[2] = fma(rec.coef[7], py[by], rec.coef[8]);
-            const double zrow = fma(rec.zp[1], py[by], rec.zp[2]);
+            float trow[3];
+            trow[0] = fmaf(t.b[0], dy[by], t.c[0]);
+            trow[1] = fmaf(t.b[1], dy[by], t.c[1]);
+            trow[2] = fmaf(t.b[2], dy[by], t.c[2]);
+            const double qrow = fma(t.zp[1], py[by], t.zp[2]);
 #pragma unroll
             for (int bx = 0; bx < 2; ++bx)
                 if ((m4 >> (2 * by + bx)) & 1u)
-                    raster_block(rec, face, px[bx], trow, zrow, zbest[2 * by + bx], fbest[2 * by + bx]);
+                    raster_block(t, recs, dx[bx], trow, px[bx], py[by], qrow, zbest[2 * by + bx], fbest[2 * by + bx]);
         }
     }
 }
@@ -300,13 +316,21 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
     __shared__ int32_t s_face[LIST_CAP];
     __shared__ uint16_t s_mask[LIST_CAP];  // bit (4*by + bx): the face's box touches block (bx, by) of the tile
     __shared__ uint32_t s_count;
-    __shared__ uint4 s_rec[64 * 8];       // the FaceRecs of the 64 list entries being rasterised
+    __shared__ uint32_t s_pre[2 * MAX_BINS + 1];       // exclusive prefix of the run lengths (nchunk <= MAX_BINS... 256 chunks)
+    __shared__ uint32_t s_run_base[2 * MAX_BINS];      // first entry of each run, relative to the scene's entries
+    __shared__ TileRec s_rec[64];          // tile-local records of the 64 list entries being rasterised
+    __shared__ int32_t s_vis[TILE_W * TILE_H];  // the tile's visibility, for the row-major resolve
 
 #ifdef DIRT_TRACE
     long long tr_t[8]; int tr_n = 0;
 #define TRACE_MARK() do { if (tr_n < 8) tr_t[tr_n++] = clock64(); } while (0)
+    long long tr_acc[4] = {0, 0, 0, 0}, tr_last = 0; int tr_cnt = 0;
+#define TRACE_ACC(i) do { long long now_ = clock64(); if ((i) > 0) tr_acc[i] += now_ - tr_last; tr_last = now_; } while (0)
+#define TRACE_CNT() do { ++tr_cnt; } while (0)
 #else
 #define TRACE_MARK() do {} while (0)
+#define TRACE_ACC(i) do {} while (0)
+#define TRACE_CNT() do {} while (0)
 #endif
     TRACE_MARK();
     const int tid = threadIdx.x;
@@ -319,12 +343,44 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
     const int tx1 = tx0 + TILE_W - 1, tr1 = tr0 + TILE_H - 1;
 
     const FaceRec* __restrict__ recs = p.recs + (size_t)ib * p.F;
-    const BinCounters* __restrict__ ctr = p.ctrs + ib;
     const int bin = (tr0 >> p.grid.shift) * p.grid.bins_x + (tx0 >> p.grid.shift);
-    const int n_bin = (int)ctr->count[bin];
-    const int n_all = n_bin + (int)ctr->big_count;
-    const BinEntry* __restrict__ bin_entries = p.entries + (size_t)ib * 4 * p.F + ctr->start[bin];
-    const BinEntry* __restrict__ big_entries = p.big + (size_t)ib * p.F;
+    // column `bin` (and the big pseudo-bin) of the chunk x bin directory: entry e of the tile's input is
+    // entry (e - s_pre[j]) of run j, where the 2 * nchunk runs are (chunk, bin) then (chunk, big)
+    const BinCell* __restrict__ cells = p.cells + (size_t)ib * p.nchunk * (MAX_BINS + 1);
+    const BinEntry* __restrict__ scene_entries = p.entries + (size_t)ib * p.nchunk * (5 * (size_t)p.chunk_faces);
+    const int nruns = 2 * p.nchunk;
+    for (int j = tid; j < nruns; j += RTHREADS) {
+        const int c = j < p.nchunk ? j : j - p.nchunk;
+        const BinCell cell = cells[(size_t)c * (MAX_BINS + 1) + (j < p.nchunk ? bin : MAX_BINS)];
+        s_run_base[j] = (uint32_t)c * (5u * (uint32_t)p.chunk_faces) + cell.start;
+        s_pre[j] = cell.count;
+    }
+    __syncthreads();
+    if (wave == 0) {  // exclusive prefix of the run lengths (<= 512 runs: 8 per lane)
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = lane * 8 + i;
+            v[i] = j < nruns ? s_pre[j] : 0u;
+            sum += v[i];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = lane * 8 + i;
+            if (j < nruns) s_pre[j] = run;
+            run += v[i];
+        }
+        if (lane == 63) s_pre[nruns] = incl;
+    }
+    __syncthreads();
+    const int n_all = (int)s_pre[nruns];
 
     // this wave's 16 x 16 region (blocks 2wx..2wx+1, 2wy..2wy+1 of the tile) and this lane's 4 pixels
     const int wx = wave & 1, wy = wave >> 1;
@@ -332,6 +388,10 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
     const int r0 = tr0 + wy * 16 + (lane >> 3);
     const double px[2] = {(double)x0 + 0.5, (double)(x0 + 8) + 0.5};
     const double py[2] = {(double)(p.H - 1 - r0) + 0.5, (double)(p.H - 1 - (r0 + 8)) + 0.5};
+    // tile-local sample coordinates (exact small integers): dx = px - (tx0 + 0.5), dy = py - py(tile's top row)
+    const float dxl[2] = {(float)(x0 - tx0), (float)(x0 + 8 - tx0)};
+    const float dyl[2] = {(float)(tr0 - r0), (float)(tr0 - (r0 + 8))};
+    const float wf = (float)p.W, hf = (float)p.H;
     // the wave's four block bits inside a 16-bit tile mask, gathered into 4 bits (2*by + bx)
     const int sh0 = (2 * wy) * 4 + 2 * wx, sh1 = (2 * wy + 1) * 4 + 2 * wx;
 
@@ -351,7 +411,13 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
             bool hit = false;
             BinEntry en;
             if (e < round_end) {
-                en = e < n_bin ? bin_entries[e] : big_entries[e - n_bin];
+                // run j with s_pre[j] <= e < s_pre[j + 1] (binary search; empty runs are skipped by the order)
+                int lo = 0, hi = nruns - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_pre[mid] <= (uint32_t)e) lo = mid; else hi = mid - 1;
+                }
+                en = scene_entries[s_run_base[lo] + ((uint32_t)e - s_pre[lo])];
                 hit = en.box.i_min <= tx1 && en.box.i_max >= tx0 && en.box.r_min <= tr1 && en.box.r_max >= tr0;
             }
             const unsigned long long m = __ballot(hit);
@@ -378,16 +444,18 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
         const int n = (int)s_count;
         TRACE_MARK();  // 5: list built
 
-        // ---- candidates, 64 at a time: their records are staged in LDS by one parallel batch of
-        //      coalesced 16-byte loads (a single memory latency for the whole tile instead of one
-        //      per candidate), then every wave walks the ones that touch its blocks ----
+        // ---- candidates, 64 at a time: one lane per candidate builds its tile-local record in LDS (one
+        //      memory latency per chunk instead of one per candidate), then every wave walks the ones that
+        //      touch its blocks; with ~64 VGPRs there are enough waves in flight to hide the LDS reads ----
         for (int cb = 0; cb < n; cb += 64) {
             const int m_chunk = min(64, n - cb);
-            for (int i = tid; i < m_chunk * 8; i += RTHREADS) {
-                const int rec = i >> 3, piece = i & 7;
-                s_rec[rec * 8 + piece] = reinterpret_cast<const uint4*>(recs + s_face[cb + rec])[piece];
+            TRACE_ACC(0);
+            if (tid < m_chunk) {
+                const int face = s_face[cb + tid];
+                make_tile_rec(recs + face, face, (double)tx0 + 0.5, (double)(p.H - 1 - tr0) + 0.5, wf, hf, &s_rec[tid]);
             }
             __syncthreads();
+            TRACE_ACC(1);
             const int idx = cb + lane;
             uint32_t mym4 = 0;
             if (idx < n) {
@@ -395,48 +463,45 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
                 mym4 = ((mk >> sh0) & 3u) | (((mk >> sh1) & 3u) << 2);
             }
             unsigned long long m = __ballot(mym4 != 0);
-            if (m) {
-                // software pipeline over the survivors: the next record's LDS reads are in flight
-                // while the current one is evaluated
-                int k = __ffsll((long long)m) - 1;
+            while (m) {
+                const int k = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                RecCore cur = *reinterpret_cast<const RecCore*>(&s_rec[k * 8]);
-                while (true) {
-                    const bool more = m != 0;
-                    const int kc = k;
-                    if (more) {
-                        k = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                    }
-                    const RecCore nxt = *reinterpret_cast<const RecCore*>(&s_rec[k * 8]);
-                    const int face = s_face[cb + kc];
-                    const uint32_t m4 = (uint32_t)__builtin_amdgcn_readlane((int)mym4, kc);
-                    raster_candidate(cur, face, m4, px, py, zbest, fbest);
-                    if (!more) break;
-                    cur = nxt;
-                }
+                const uint32_t m4 = (uint32_t)__builtin_amdgcn_readlane((int)mym4, k);
+                const TileRec t = s_rec[k];
+                raster_candidate(t, recs, m4, dxl, dyl, px, py, zbest, fbest);
+                TRACE_CNT();
             }
+            TRACE_ACC(2);
             __syncthreads();
+            TRACE_ACC(3);
         }
     }
 
     TRACE_MARK();  // 6: candidates done
-    // ---- resolve: shade (MODE 0) or export the visibility buffer (MODE 1) ----
+
+    // ---- resolve through an LDS visibility tile: the per-lane results are scattered to it, then the 256
+    //      threads walk the tile row-major (32 consecutive pixels of a row per half-wave: coalesced HWC
+    //      stores) to export visibility and / or shade ----
 #pragma unroll
     for (int by = 0; by < 2; ++by)
 #pragma unroll
-        for (int bx = 0; bx < 2; ++bx) {
-            const int x = x0 + 8 * bx, r = r0 + 8 * by;
-            if (r >= p.H || x >= p.W) continue;
-            const int32_t f = fbest[2 * by + bx];
-            if (MODE == 1 || p.vis) p.vis[((size_t)ib * p.H + r) * p.W + x] = f;
-            if (MODE == 0) shade_pixel(p, recs, ib, x, r, px[bx], py[by], f);
-        }
+        for (int bx = 0; bx < 2; ++bx)
+            s_vis[(wy * 16 + by * 8 + (lane >> 3)) * TILE_W + wx * 16 + bx * 8 + (lane & 7)] = fbest[2 * by + bx];
+    __syncthreads();
+#pragma unroll 1
+    for (int i = tid; i < TILE_W * TILE_H; i += RTHREADS) {
+        const int x = tx0 + (i & (TILE_W - 1)), r = tr0 + (i >> 5);
+        if (r >= p.H || x >= p.W) continue;
+        const int32_t f = s_vis[i];
+        if (MODE == 1 || p.vis) p.vis[((size_t)ib * p.H + r) * p.W + x] = f;
+        if (MODE == 0) shade_pixel(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
+    }
     TRACE_MARK();  // 7: stored
 #ifdef DIRT_TRACE
     if (lane == 0 && g_trace_buf) {
         long long* o = g_trace_buf + ((size_t)blockIdx.x * 4 + wave) * 8;
         for (int i = 0; i < 8; ++i) o[i] = tr_t[i];
+        o[1] = tr_acc[1]; o[2] = tr_acc[2]; o[3] = tr_acc[3]; o[4] = tr_cnt;
     }
 #endif
 }
@@ -466,10 +531,9 @@ hipError_t launch_zero(void* b, size_t b_bytes, void* c, size_t c_bytes, hipStre
 hipError_t launch_geometry(const GeomParams& g, hipStream_t stream)
 {
     if (g.B == 0) return hipSuccess;
-    // also with F == 0: fill publishes the (all-zero) directory the raster kernel reads
+    // also with F == 0: the (all-zero) directory row is what the raster kernel reads
     const dim3 grid((unsigned)g.nchunk, (unsigned)g.B);
     hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, stream, g);
-    hipLaunchKernelGGL(fill_kernel, grid, dim3(256), 0, stream, g);
     return hipGetLastError();
 }
 
