@@ -87,20 +87,28 @@ __device__ inline bool setup_face(const float* __restrict__ verts, int V, const 
     if (npos == 3) {
         if (Z[0] > Wc[0] && Z[1] > Wc[1] && Z[2] > Wc[2]) return false;
         if (Z[0] < -Wc[0] && Z[1] < -Wc[1] && Z[2] < -Wc[2]) return false;
-        double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        // window-space box in float32: three reciprocals instead of six f64 divisions.  The box is only a
+        // work-skipping device (coverage is decided by the edge functions), so it just has to be
+        // conservative: float rounding (2^-22 relative on |x| <= 32768 px) is covered by the 1/32 px margin,
+        // anything larger is outside the frame on that side anyway.
+        float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
         for (int k = 0; k < 3; ++k) {
-            const double xw = X[k] / Wc[k], yw = Y[k] / Wc[k];
-            xmin = fmin(xmin, xw); xmax = fmax(xmax, xw);
-            ymin = fmin(ymin, yw); ymax = fmax(ymax, yw);
+            const float rw = 1.0f / (float)Wc[k];
+            float xw = (float)X[k] * rw, yw = (float)Y[k] * rw;
+            if (!(fabsf(xw) <= 32768.f)) xw = xw > 0.f ? 32768.f : -32768.f;  // also catches inf / NaN of tiny w
+            if (!(fabsf(yw) <= 32768.f)) yw = yw > 0.f ? 32768.f : -32768.f;
+            xmin = fminf(xmin, xw); xmax = fmaxf(xmax, xw);
+            ymin = fminf(ymin, yw); ymax = fmaxf(ymax, yw);
         }
-        const double d = 1.0 / 1024.0;
-        double lo, hi;
-        lo = ceil(fmax(xmin - 0.5 - d, -1.0)); hi = floor(fmin(xmax - 0.5 + d, (double)W));
-        if (lo > (double)i_min) i_min = (int)lo;
-        if (hi < (double)i_max) i_max = (int)hi;
-        lo = ceil(fmax(ymin - 0.5 - d, -1.0)); hi = floor(fmin(ymax - 0.5 + d, (double)H));
-        if (lo > (double)j_min) j_min = (int)lo;
-        if (hi < (double)j_max) j_max = (int)hi;
+        if (!(xmin <= xmax) || !(ymin <= ymax)) { xmin = ymin = -32768.f; xmax = ymax = 32768.f; }  // NaN: keep everything
+        const float d = 1.0f / 32.0f;
+        float lo, hi;
+        lo = ceilf(fmaxf(xmin - 0.5f - d, -1.0f)); hi = floorf(fminf(xmax - 0.5f + d, (float)W));
+        if (lo > (float)i_min) i_min = (int)lo;
+        if (hi < (float)i_max) i_max = (int)hi;
+        lo = ceilf(fmaxf(ymin - 0.5f - d, -1.0f)); hi = floorf(fminf(ymax - 0.5f + d, (float)H));
+        if (lo > (float)j_min) j_min = (int)lo;
+        if (hi < (float)j_max) j_max = (int)hi;
     }
     if (i_min > i_max || j_min > j_max) return false;
 
