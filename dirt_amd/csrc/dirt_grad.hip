@@ -186,7 +186,7 @@ __device__ __forceinline__ void fix_add(unsigned long long* acc, const Target& t
 }
 
 // Index-triple comparison of two faces through their records (only when the slot table is full).
-__device__ __noinline__ bool triple_differs_global(const FaceRec* __restrict__ recs, int fa, int fb)
+__device__ __forceinline__ bool triple_differs_global(const FaceRec* __restrict__ recs, int fa, int fb)
 {
     return recs[fa].vid[0] != recs[fb].vid[0] || recs[fa].vid[1] != recs[fb].vid[1] || recs[fa].vid[2] != recs[fb].vid[2];
 }
@@ -212,7 +212,7 @@ __device__ __forceinline__ void scharr_taps(const float* c, float& sx, float& sy
 // The same from global memory for an aliased (quirk Q1) channel whose taps run past the end of the
 // image row: `centre` is the flat pixel index of the tap centre in the [B,H,W] slice; reads past the end
 // of the tensor are clamped to its last element (undefined in the reference).  Rare: kept out of line.
-__device__ __noinline__ float2 scharr_taps_wrapped(const float* __restrict__ pixels, size_t total_pix, size_t centre, int W,
+__device__ __forceinline__ float2 scharr_taps_wrapped(const float* __restrict__ pixels, size_t total_pix, size_t centre, int W,
                                                    int C, int c)
 {
     float sx, sy;
@@ -420,6 +420,7 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
         const int32_t face_here = inside ? s_vis[py_l][px_l] : -1;
         const int slot_here = inside ? (int)s_slot[py_l][px_l] : -1;
         const Target t_here = make_target(slot_here, lane);
+        const int hv0 = s_vid[max(slot_here, 0)][0], hv1 = s_vid[max(slot_here, 0)][1], hv2 = s_vid[max(slot_here, 0)][2];
         const float4 fh4 = s_frag[py_l][px_l];
 
         // ---- background gradient (:143-147) and colour gradients (:135-142) of the pass's channels ----
@@ -435,22 +436,22 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
             }
         }
         {
-            const float hb[3] = {fh4.x, fh4.y, fh4.z};
-            float cv[3 * PC];
+            const bool col_lds = finite && slot_here != -2;
+            const bool col_direct = !col_lds && face_here >= 0 && (t_here.active || slot_here == -2);
+#pragma unroll 1
+            for (int k = 0; k < 3; ++k) {
+                const float hbk = k == 0 ? fh4.x : (k == 1 ? fh4.y : fh4.z);
+                float cv[PC];
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int c = 0; c < PC; ++c)
-                    cv[k * PC + c] = quad_reduce(t_here, (face_here >= 0 && c < nch) ? gch[c] * hb[k] : 0.f);
-            if (finite && slot_here != -2) {
-                fix_add<3 * PC>(s_acc, t_here, 9, cv, fc.to_fix);
-            } else if (face_here >= 0 && (t_here.active || slot_here == -2)) {
-                // table full, or inf / NaN in the tile: the reference's direct float atomics
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
+                for (int c = 0; c < PC; ++c) cv[c] = quad_reduce(t_here, (face_here >= 0 && c < nch) ? gch[c] * hbk : 0.f);
+                if (col_lds) {
+                    fix_add<PC>(s_acc, t_here, 9 + k * PC, cv, fc.to_fix);
+                } else if (col_direct) {
+                    // table full, or inf / NaN in the tile: the reference's direct float atomics
 #pragma unroll
                     for (int c = 0; c < PC; ++c)
-                        if (c < nch) atomicAdd(&grad_vertex_colors[(size_t)recs[face_here].vid[k] * C + c0 + c], cv[k * PC + c]);
+                        if (c < nch) atomicAdd(&grad_vertex_colors[(size_t)recs[face_here].vid[k] * C + c0 + c], cv[c]);
+                }
             }
         }
 
@@ -461,68 +462,71 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
             const int G = (c_begin + 3 <= C) ? 3 : 1;
             const bool alias = (G == 1) && !q1_intended;  // quirk Q1: "channels" 1,2 of a 1-channel tensor
 
-            // Scharr, :126-127 (negative-offset minus positive-offset; offset_y is up)
-            float sx[3], sy[3];
-#pragma unroll
+            // Scharr (:126-127), streamed per channel into what is needed of it: the L1 norms of :185 (all three
+            // "channels" of the reference's Vec3, in its summation order) and dL/dx, dL/dy of :203-208 (the
+            // group's real channels, in channel order)
+            float l1x = 0.f, l1y = 0.f, dL_dx = 0.f, dL_dy = 0.f;
+#pragma unroll 1
             for (int ch = 0; ch < 3; ++ch) {
-                sx[ch] = 0.f; sy[ch] = 0.f;
-                if (ch < G) scharr_taps(&s_pix[cg + ch][py_l][px_l], sx[ch], sy[ch]);
-            }
-            if (alias) {
-                // quirk Q1: "channels" 1,2 of a 1-channel group = elements (pixel + ch) of the flattened
-                // [B,H,W,1] slice.  Only the L1 norms of interior pixels use them, and for an interior
-                // pixel the taps are unclamped: column + ch, which is staged unless it runs past the end
-                // of the image row (then it wraps to the next row: read from global memory).
-#pragma unroll
-                for (int ch = 1; ch < 3; ++ch) {
-                    if (x_in_frame + 1 + ch <= W - 1 || !interior) {
-                        scharr_taps(&s_pix[cg][py_l][min(px_l + ch, PW - 2)], sx[ch], sy[ch]);
-                    } else {
-                        const float2 w2 = scharr_taps_wrapped(p.pixels, total_pix,
-                                                              (size_t)iib * frame + (size_t)y_in_frame * W + x_in_frame + ch, W, C, c_begin);
-                        sx[ch] = w2.x; sy[ch] = w2.y;
+                float sxc = 0.f, syc = 0.f;
+                if (ch < G) {
+                    scharr_taps(&s_pix[cg + ch][py_l][px_l], sxc, syc);
+                    const float gcv = (cg + ch == 0) ? gch[0] : (cg + ch == 1) ? gch[1] : (cg + ch == 2) ? gch[2] : gch[3];
+                    float m = gcv * sxc;
+                    dL_dx = dL_dx + m;
+                    m = gcv * syc;
+                    dL_dy = dL_dy + m;
+                } else if (alias) {
+                    // quirk Q1: "channels" 1,2 of a 1-channel group = elements (pixel + ch) of the flattened
+                    // [B,H,W,1] slice.  Only the L1 norms of interior pixels use them, and for an interior pixel
+                    // the taps are unclamped: column + ch, which is staged unless it runs past the end of the
+                    // image row (then it wraps to the next row: read from global memory).
+                    scharr_taps(&s_pix[cg][py_l][min(px_l + ch, PW - 2)], sxc, syc);
+                    const bool wraps = interior && x_in_frame + 1 + ch > W - 1;
+                    if (__ballot(wraps) != 0ull) {  // only tiles on the right image border
+                        if (wraps) {
+                            const float2 w2 = scharr_taps_wrapped(p.pixels, total_pix,
+                                                                  (size_t)iib * frame + (size_t)y_in_frame * W + x_in_frame + ch, W, C, c_begin);
+                            sxc = w2.x; syc = w2.y;
+                        }
                     }
                 }
+                if (!(G == 1 && q1_intended && ch > 0)) { l1x = l1x + fabsf(sxc); l1y = l1y + fabsf(syc); }
             }
-
             GMARK();  // scharr
-            // dilation, :155-194: which pixel's (barycentric, indices, clip_w) this pixel uses
+            // dilation, :155-194: which pixel's (barycentric, indices, clip_w) this pixel uses.  Both candidate
+            // neighbours are read unconditionally (LDS) and the choice is predicated -- no divergent branches.
             int cy_l = py_l, cx_l = px_l;  // position (in the halo'd tile) of the fragment used
             bool dilated = false;
-            if (interior) {
-                float l1x, l1y;
-                if (G == 1 && q1_intended) {
-                    l1x = fabsf(sx[0]); l1y = fabsf(sy[0]);
-                } else {
-                    l1x = (fabsf(sx[0]) + fabsf(sx[1])) + fabsf(sx[2]);
-                    l1y = (fabsf(sy[0]) + fabsf(sy[1])) + fabsf(sy[2]);
-                }
-                int off_x = l1x > l1y ? 1 : 0, off_y = l1x > l1y ? 0 : 1;
-                if (((x_in_frame + y_in_frame) & 1) == 1) { off_x = -off_x; off_y = -off_y; }
+            {
+                int off_x = l1x > l1y ? 1 : 0, off_y = l1x > l1y ? 0 : 1;                    // :185
+                if (((x_in_frame + y_in_frame) & 1) == 1) { off_x = -off_x; off_y = -off_y; }  // :186-190
+                // the reference offsets in GL buffer orientation (y up): tensor row = y - offset_y
+                const int y1 = py_l - off_y, x1 = px_l + off_x, y2 = py_l + off_y, x2 = px_l - off_x;
+                const int32_t f1 = s_vis[y1][x1], f2 = s_vis[y2][x2];
+                const int s1 = s_slot[y1][x1], s2 = s_slot[y2][x2];
+                const float w1 = s_frag[y1][x1].w, w2 = s_frag[y2][x2].w;
                 const float w_here = fh4.w;
-#pragma unroll
-                for (int attempt = 0; attempt < 2; ++attempt) {
-                    if (dilated) break;
-                    // the reference offsets in GL buffer orientation (y up): tensor row = y - offset_y
-                    const int ny = py_l - (attempt == 0 ? off_y : -off_y), nx = px_l + (attempt == 0 ? off_x : -off_x);
-                    const int32_t face_off = s_vis[ny][nx];
-                    if (face_off >= 0 && face_off != face_here) {
-                        // index triples: equal faces have equal triples; distinct faces are compared by vertex index
-                        const int s_o = s_slot[ny][nx];
-                        bool differs = true;
-                        if (face_here >= 0) {
-                            if (slot_here >= 0 && s_o >= 0)
-                                differs = s_vid[slot_here][0] != s_vid[s_o][0] || s_vid[slot_here][1] != s_vid[s_o][1] ||
-                                          s_vid[slot_here][2] != s_vid[s_o][2];
-                            else  // a face without a slot (table full): compare through the records
-                                differs = triple_differs_global(recs, face_here, face_off);
-                        }
-                        if (differs && w_here > s_frag[ny][nx].w) {  // :165
-                            cy_l = ny; cx_l = nx;
-                            dilated = true;
-                        }
+                // index triples differ (:86-89): an uncovered pixel (-1,-1,-1) differs from any face; two faces
+                // with slots compare by canonical slot; a face without a slot (table full) through its record
+                bool d1 = f1 >= 0 && f1 != face_here, d2 = f2 >= 0 && f2 != face_here;
+                if (face_here >= 0) {
+                    // distinct faces over the same three vertices count as equal (:86-89): compare the triples
+                    const int c1 = max(s1, 0), c2 = max(s2, 0);
+                    const bool t1 = s_vid[c1][0] != hv0 || s_vid[c1][1] != hv1 || s_vid[c1][2] != hv2;
+                    const bool t2 = s_vid[c2][0] != hv0 || s_vid[c2][1] != hv1 || s_vid[c2][2] != hv2;
+                    const bool g1 = d1 && (slot_here < 0 || s1 < 0), g2 = d2 && (slot_here < 0 || s2 < 0);
+                    d1 = d1 && t1; d2 = d2 && t2;
+                    if (__ballot(g1 || g2) != 0ull) {  // some face has no slot (table full): compare through the records
+                        if (g1) d1 = triple_differs_global(recs, face_here, f1);
+                        if (g2) d2 = triple_differs_global(recs, face_here, f2);
                     }
                 }
+                const bool ok1 = interior && d1 && w_here > w1;          // :165, first attempt (:191)
+                const bool ok2 = interior && !ok1 && d2 && w_here > w2;  // opposite direction if the first failed (:192-193)
+                dilated = ok1 || ok2;
+                cy_l = ok1 ? y1 : (ok2 ? y2 : py_l);
+                cx_l = ok1 ? x1 : (ok2 ? x2 : px_l);
             }
 
             if (p.debug_thingy && c_begin == 0 && inside) {  // :150-151,172
@@ -544,18 +548,6 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
             const int slot_cur = covered ? (int)s_slot[cy_l][cx_l] : -1;
             const Target t_cur = make_target(slot_cur, lane);
             const float4 fc4 = s_frag[cy_l][cx_l];
-            const float cb[3] = {fc4.x, fc4.y, fc4.z};
-            float dL_dx = 0.f, dL_dy = 0.f;
-#pragma unroll
-            for (int channel = 0; channel < 3; ++channel) {
-                if (channel < G) {
-                    const float gcv = (cg + channel == 0) ? gch[0] : (cg + channel == 1) ? gch[1] : (cg + channel == 2) ? gch[2] : gch[3];
-                    float m = gcv * sx[channel];
-                    dL_dx = dL_dx + m;
-                    m = gcv * sy[channel];
-                    dL_dy = dL_dy + m;
-                }
-            }
             // clip-space x,y of the fragment used (:210-215 sums b_k * vertex_k.xy; perspective-correct
             // barycentrics make that sum the fragment's own clip position = its NDC position times clip_w,
             // so no vertex gather is needed; agrees to float rounding)
@@ -570,26 +562,25 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
             const float rcp_ww = rcp_w * rcp_w;
             const float d_xview_by_wclip = ((-.5f * width_f) * clip_x) * rcp_ww;
             const float d_yview_by_wclip = ((-.5f * height_f) * clip_y) * rcp_ww;
-            float pv[9];
-#pragma unroll
+            const bool pos_lds = finite && slot_cur != -2;
+            const bool pos_direct = !pos_lds && covered && (t_cur.active || slot_cur == -2);
+#pragma unroll 1
             for (int k = 0; k < 3; ++k) {
-                const float dLx_b = dL_dx * cb[k];
-                const float dLy_b = dL_dy * cb[k];
+                const float cbk = k == 0 ? fc4.x : (k == 1 ? fc4.y : fc4.z);
+                const float dLx_b = dL_dx * cbk;
+                const float dLy_b = dL_dy * cbk;
                 const float gw1 = dLx_b * d_xview_by_wclip, gw2 = dLy_b * d_yview_by_wclip;
-                pv[k * 3 + 0] = quad_reduce(t_cur, covered ? dLx_b * d_xview_by_xclip : 0.f);
-                pv[k * 3 + 1] = quad_reduce(t_cur, covered ? dLy_b * d_yview_by_yclip : 0.f);
-                pv[k * 3 + 2] = quad_reduce(t_cur, covered ? gw1 + gw2 : 0.f);
-            }
-            GMARK();  // position math + quad
-            if (finite && slot_cur != -2) {
-                fix_add<9>(s_acc, t_cur, 0, pv, fp.to_fix);
-            } else if (covered && (t_cur.active || slot_cur == -2)) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
+                float pv[3];
+                pv[0] = quad_reduce(t_cur, covered ? dLx_b * d_xview_by_xclip : 0.f);
+                pv[1] = quad_reduce(t_cur, covered ? dLy_b * d_yview_by_yclip : 0.f);
+                pv[2] = quad_reduce(t_cur, covered ? gw1 + gw2 : 0.f);
+                if (pos_lds) {
+                    fix_add<3>(s_acc, t_cur, 3 * k, pv, fp.to_fix);
+                } else if (pos_direct) {
                     float* gv = grad_vertices + (size_t)recs[face_cur].vid[k] * 4;
-                    atomicAdd(gv + 0, pv[k * 3 + 0]);
-                    atomicAdd(gv + 1, pv[k * 3 + 1]);
-                    atomicAdd(gv + 3, pv[k * 3 + 2]);
+                    atomicAdd(gv + 0, pv[0]);
+                    atomicAdd(gv + 1, pv[1]);
+                    atomicAdd(gv + 3, pv[2]);
                 }
             }
             GMARK();  // fix_add
