@@ -61,6 +61,7 @@ constexpr int NVAL = 9 + 3 * PC;       // 9 position values (3 vertices x {x,y,w
 #ifndef GRAD_WAVES_PER_SIMD
 #define GRAD_WAVES_PER_SIMD 4
 #endif
+static_assert(MAX_SLOTS == 64, "the slot bookkeeping uses one wave for the table");
 constexpr int FIX_BITS = 29;           // fixed-point contributions: |q| < 2^FIX_BITS given the tile bound
 
 struct Frag {
@@ -241,6 +242,8 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
     __shared__ int16_t s_slot[PH][VW];                               // and that face's slot (-1 none, -2 table full)
     __shared__ int32_t s_key[MAX_SLOTS];                             // slot -> face
     __shared__ int32_t s_vid[MAX_SLOTS][3];                          // slot -> the face's vertex indices
+    __shared__ uint8_t s_used[MAX_SLOTS];                             // compacted list of the occupied slots
+    __shared__ int s_nused;
     __shared__ uint32_t s_bound[3];                                  // tile maxima (float bits): |grad_pixels|, |pixels|, 1/clip_w
 
 #ifdef DIRT_TRACE
@@ -316,10 +319,6 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
 
     // ---- init ----
     for (int i = tid; i < MAX_SLOTS; i += GTHREADS) s_key[i] = -1;
-    {
-        uint4* z = reinterpret_cast<uint4*>(s_acc);  // 16-byte stores
-        for (int i = tid; i < MAX_SLOTS * NVAL * COPIES / 2; i += GTHREADS) z[i] = make_uint4(0, 0, 0, 0);
-    }
     if (tid < 3) s_bound[tid] = 0u;
     __syncthreads();
     GMARK();  // 1 init
@@ -399,13 +398,27 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
         }
         __syncthreads();
         GMARK();  // 3 staged
-        if (tid < MAX_SLOTS && c0 == 0) {
-            const int32_t face = s_key[tid];
-            if (face >= 0) {
-                s_vid[tid][0] = recs[face].vid[0]; s_vid[tid][1] = recs[face].vid[1]; s_vid[tid][2] = recs[face].vid[2];
+        if (c0 == 0) {
+            // the slot table is complete: fetch the vertex indices of the occupied slots, list them, and clear
+            // only their accumulators (typically ~20 of 64 slots are in use)
+            if (wave == 0) {
+                const int32_t face = s_key[lane];  // MAX_SLOTS == 64 == one wave
+                const bool used = face >= 0;
+                const unsigned long long um = __ballot(used);
+                if (used) {
+                    s_vid[lane][0] = recs[face].vid[0]; s_vid[lane][1] = recs[face].vid[1]; s_vid[lane][2] = recs[face].vid[2];
+                    s_used[__popcll(um & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+                }
+                if (lane == 0) s_nused = __popcll(um);
             }
+            __syncthreads();
+            const int nused = s_nused;
+            for (int i = tid; i < nused * (NVAL * COPIES / 2); i += GTHREADS) {
+                const int u = i / (NVAL * COPIES / 2), j = i - u * (NVAL * COPIES / 2);
+                reinterpret_cast<uint4*>(s_acc)[(int)s_used[u] * (NVAL * COPIES / 2) + j] = make_uint4(0, 0, 0, 0);
+            }
+            __syncthreads();
         }
-        if (c0 == 0) __syncthreads();
         GMARK();  // 4 vids
 
         // ---- fixed-point scales from tile-wide bounds (no data-dependent barrier needed):
@@ -590,10 +603,11 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
         __syncthreads();
 
         // ---- flush: one global atomic per (face, vertex, component) for the whole tile and pass ----
-        for (int e = tid; e < MAX_SLOTS * NVAL; e += GTHREADS) {
-            const int slot = e / NVAL, v = e - slot * NVAL;
-            if (s_key[slot] < 0) continue;
-            unsigned long long* a = &s_acc[e * COPIES];
+        const int nused_f = s_nused;
+        for (int e = tid; e < nused_f * NVAL; e += GTHREADS) {
+            const int u = e / NVAL, v = e - u * NVAL;
+            const int slot = s_used[u];
+            unsigned long long* a = &s_acc[(slot * NVAL + v) * COPIES];
             long long sum = 0;
 #pragma unroll
             for (int cp = 0; cp < COPIES; ++cp) { sum += (long long)a[cp]; a[cp] = 0ull; }
