@@ -10,15 +10,15 @@
 // Structure of raster_kernel (one 256-thread workgroup = one 32x32 pixel tile of one scene = 4x4
 // blocks of 8x8 pixels; each of its 4 waves owns a 16x16 region = 2x2 blocks, 4 pixels per lane, so
 // that one record fetch serves 256 pixels):
-//   scan   : the threads stride over the face list of the tile's bin (plus the scene's big list)
-//            and append the faces whose box touches the tile to an LDS list (wave-aggregated LDS
-//            atomic), together with a 16-bit mask of the blocks the box touches;
-//   raster : each wave tests 64 list entries at a time against its four block bits (ballot -> 64-bit
-//            survivor mask); survivors are visited with a scalar bit-scan, their record fetched with
-//            wave-uniform (scalar) loads so the nine f64 edge coefficients sit in SGPRs, the next
-//            survivor's loads in flight while the current one is evaluated; each lane evaluates the
-//            three edge functions at its pixel centre exactly as the specification writes them,
-//            then depth, then a (z24, face) lexicographic min held in registers -- no LDS or global
+//   scan   : the threads walk column `bin` of the chunk x bin directory (binary search over the run
+//            prefix held in LDS) and append the faces whose box touches the tile to an LDS list
+//            (wave-aggregated LDS atomic), together with a 16-bit mask of the blocks the box touches;
+//   raster : 64 candidates at a time are staged in LDS as TileRecs (one lane per candidate: float32
+//            tile-local edge coefficients + certified error bounds + the f64 depth plane); every wave
+//            then visits the candidates whose mask touches one of its four blocks: float32 edge
+//            functions classify each sample as certainly inside / certainly outside, the few in
+//            between take the specification's f64 test (covered_exact); then depth from the f64
+//            plane and a (z24, face) lexicographic min held in registers -- no LDS or global
 //            atomics, and the result is independent of list order;
 //   shade  : the winner's record is re-read per pixel, barycentrics and all C channels are
 //            interpolated once, and the HWC pixel is written (background copied where uncovered).
@@ -539,8 +539,7 @@ hipError_t launch_geometry(const GeomParams& g, hipStream_t stream)
 
 void chunking(int F, int& nchunk, int& chunk_faces)
 {
-    // <= 256 chunks of >= 256 faces: the count matrix stays small enough for every fill workgroup
-    // to read all of it
+    // <= 256 chunks of >= 256 faces: a raster tile reads one directory cell per chunk (2 * nchunk <= 512 runs)
     chunk_faces = 256;
     if ((long long)chunk_faces * 256 < F) chunk_faces = (F + 255) / 256;
     nchunk = F > 0 ? (F + chunk_faces - 1) / chunk_faces : 1;

@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import pmc_summary  # noqa: E402
 
 SLOT = {'grad_kernel': 'grad_kernel', 'raster_kernel<0>': 'raster_kernel<shade>', 'raster_kernel<1>': 'raster_kernel<visibility>',
-        'setup_kernel': 'setup_kernel', 'fill_kernel': 'fill_kernel', 'zero_kernel': 'zero_kernel'}
+        'setup_kernel': 'setup_kernel', 'zero_kernel': 'zero_kernel'}
 
 
 def counter(path, name):
