@@ -47,14 +47,20 @@ extern "C" void dirt_debug_set_trace_grad(void* p)
 #define GMARK() do {} while (0)
 #endif
 
-constexpr int GW = 32, GH = 16;        // tile = 32 x 16 pixels, one pixel per lane
-constexpr int GTHREADS = 512;          // 8 waves = 4 x 2 blocks of 8 x 8 pixels
+#ifndef GRAD_TILE_H
+#define GRAD_TILE_H 16
+#endif
+#ifndef GRAD_COPIES
+#define GRAD_COPIES 4
+#endif
+constexpr int GW = 32, GH = GRAD_TILE_H;  // tile = 32 x 16 pixels, one pixel per lane
+constexpr int GTHREADS = GW * GH;      // 8 waves = 4 x 2 blocks of 8 x 8 pixels
 constexpr int PWU = GW + 4;            // staged `pixels` columns: x0-1 .. x0+34 (halo + 2 for the Q1 alias taps)
 constexpr int PW = 40;                 // ... padded: row stride = 8 (mod 32) dwords keeps an 8x8 block's reads conflict free
 constexpr int PH = GH + 2;             // staged rows: y0-1 .. y0+16
 constexpr int VWU = GW + 2;            // visibility tile with a 1-pixel halo
 constexpr int VW = 40;                 // ... padded likewise (32 (mod 64) dwords for the float4 rows)
-constexpr int COPIES = 4;              // accumulator replicas per (slot, value)
+constexpr int COPIES = GRAD_COPIES;    // accumulator replicas per (slot, value)
 constexpr int MAX_SLOTS = 64;          // slot table capacity (LDS)
 constexpr int PC = 4;                  // channels per pass: whole channel groups that fit in 4 channels
 constexpr int NVAL = 9 + 3 * PC;       // 9 position values (3 vertices x {x,y,w}) + 3 vertices x PC colour values
@@ -263,6 +269,7 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
 
     const FaceRec* __restrict__ recs = p.recs + (size_t)iib * p.F;
     const int32_t* __restrict__ vis = p.vis + (size_t)iib * frame;
+    const float4* __restrict__ frag = p.frag + (size_t)iib * frame;
     const float* __restrict__ pixels = p.pixels + (size_t)iib * frame * C;
     float* __restrict__ grad_vertices = p.grad_vertices + (size_t)iib * p.V * 4;
     float* __restrict__ grad_vertex_colors = p.grad_vertex_colors + (size_t)iib * p.V * C;
@@ -317,6 +324,23 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
         for (int c = 0; c < PC; ++c) g0v[c] = c < nch0 ? g_here[c] : 0.f;
     }
 
+    // so is the visibility of the halo'd tile: PH * VWU positions, APOS per thread
+    constexpr int APOS = (PH * VWU + GTHREADS - 1) / GTHREADS;
+    int32_t a_face[APOS];
+    float4 a_frag[APOS];
+#pragma unroll
+    for (int j = 0; j < APOS; ++j) {
+        const int i = tid + j * GTHREADS;
+        a_face[j] = -1;
+        a_frag[j] = make_float4(-1.f, -1.f, -1.f, INFINITY);
+        if (i < PH * VWU) {
+            const int vy = i / VWU, vx = i - vy * VWU;
+            const int rr = min(max(tr0 + vy - 1, 0), H - 1), xx = min(max(tx0 + vx - 1, 0), W - 1);
+            a_face[j] = vis[(size_t)rr * W + xx];
+            a_frag[j] = frag[(size_t)rr * W + xx];
+        }
+    }
+
     // ---- init ----
     for (int i = tid; i < MAX_SLOTS; i += GTHREADS) s_key[i] = -1;
     if (tid < 3) s_bound[tid] = 0u;
@@ -327,25 +351,25 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
     //      shader writes (csrc/shaders.cpp:64-77) over the clear values of
     //      csrc/rasterise_grad_egl.cpp:442-445.  Halo positions outside the frame are clamped; they
     //      are only ever consulted for interior pixels, whose neighbours are inside the frame. ----
-    float rcpw_max = 0.f;
-    for (int i = tid; i < PH * VWU; i += GTHREADS) {
+    float w_min = INFINITY;
+#pragma unroll
+    for (int j = 0; j < APOS; ++j) {
+        const int i = tid + j * GTHREADS;
+        if (i >= PH * VWU) continue;
         const int vy = i / VWU, vx = i - vy * VWU;
-        const int rr = min(max(tr0 + vy - 1, 0), H - 1), xx = min(max(tx0 + vx - 1, 0), W - 1);
-        const int32_t face = vis[(size_t)rr * W + xx];
-        float4 fr = make_float4(-1.f, -1.f, -1.f, INFINITY);
+        const int32_t face = a_face[j];
         int slot = -1;
         if (face >= 0) {
-            const Frag f = frag_eval(recs, face, xx, rr, H);
-            fr = make_float4(f.b[0], f.b[1], f.b[2], f.w);
-            rcpw_max = fmaxf(rcpw_max, fabsf(1.0f / f.w));
+            w_min = fminf(w_min, fabsf(a_frag[j].w));
             slot = slot_insert(s_key, MAX_SLOTS, face);
             if (slot < 0) slot = -2;
         }
         s_vis[vy][vx] = face;
-        s_frag[vy][vx] = fr;
+        s_frag[vy][vx] = a_frag[j];
         s_slot[vy][vx] = (int16_t)slot;
     }
     {
+        const float rcpw_max = __builtin_amdgcn_rcpf(w_min);  // a bound (used with 2x slack): 1 ulp is plenty
         const uint32_t m = wave_max_u32(__float_as_uint(rcpw_max));
         if (lane == 0 && m) atomicMax(&s_bound[2], m);
     }
@@ -568,8 +592,8 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
             const float ndc_x = ((float)(tx0 + cx_l - 1) + 0.5f) * (2.f / width_f) - 1.f;
             const float ndc_y = ((float)(H - 1 - (tr0 + cy_l - 1)) + 0.5f) * (2.f / height_f) - 1.f;
             const float clip_x = ndc_x * clip_w, clip_y = ndc_y * clip_w;
-            // :219-222 with one reciprocal instead of four divisions
-            const float rcp_w = 1.0f / clip_w;
+            // :219-222 with one reciprocal (v_rcp_f32, 1 ulp) instead of four divisions
+            const float rcp_w = __builtin_amdgcn_rcpf(clip_w);
             const float d_xview_by_xclip = (.5f * width_f) * rcp_w;
             const float d_yview_by_yclip = (.5f * height_f) * rcp_w;
             const float rcp_ww = rcp_w * rcp_w;

@@ -53,6 +53,7 @@ struct RasterParams {
     const float* vertex_colors;  // [B,V,C]
     float* pixels;               // [B,H,W,C]
     int32_t* vis;                // [B,H,W] visibility export (MODE 1; optional in MODE 0)
+    float4* frag;                // [B,H,W] (b0,b1,b2,clip_w) of the front-most fragment, exported with vis for the backward pass; or nullptr
     int V, F, H, W, C;
     BinGrid grid;
     int tiles_x, tiles_y;        // filled by launch_raster
@@ -61,6 +62,7 @@ struct RasterParams {
 struct GradParams {
     const FaceRec* recs;       // [B*F]
     const int32_t* vis;        // [B,H,W] front-most face or -1
+    const float4* frag;        // [B,H,W] its (b0,b1,b2,clip_w): the backward fragment shader's output, csrc/shaders.cpp:64-77
     const float* vertices;     // [B,V,4]
     const float* pixels;       // [B,H,W,C]
     const float* grad_pixels;  // [B,H,W,C]

@@ -264,6 +264,25 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles)
     return x * q + min(x, rem) + j;
 }
 
+// The backward pass's fragment of one pixel, (b0, b1, b2, clip_w): csrc/shaders.cpp:64-77.
+__device__ __forceinline__ void export_frag(const RasterParams& p, const FaceRec* __restrict__ recs, int ib, int x, int r,
+                                            double px, double py, int32_t f)
+{
+    float4 fr = make_float4(-1.f, -1.f, -1.f, INFINITY);
+    if (f >= 0) {
+        const FaceRec* __restrict__ rec = recs + f;
+        double cf[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cf[k] = rec->coef[k];
+        double Fk[3];
+        edge_eval(cf, px, py, Fk);
+        float b[3], cw;
+        bary_eval(Fk, rec->flags, rec->inv_det, b, cw);
+        fr = make_float4(b[0], b[1], b[2], cw);
+    }
+    p.frag[((size_t)ib * p.H + r) * p.W + x] = fr;
+}
+
 // Shade one pixel: the winner's record is re-read, barycentrics and all C channels interpolated once.
 __device__ __forceinline__ void shade_pixel(const RasterParams& p, const FaceRec* __restrict__ recs, int ib, int x, int r,
                                             double px, double py, int32_t f)
@@ -272,6 +291,7 @@ __device__ __forceinline__ void shade_pixel(const RasterParams& p, const FaceRec
     const int C = p.C;
     float* __restrict__ out = p.pixels + pix * C;
     if (f < 0) {  // pixels start as the background: csrc/rasterise_egl.cpp:348-356
+        if (p.frag) p.frag[pix] = make_float4(-1.f, -1.f, -1.f, INFINITY);  // clear values, csrc/rasterise_grad_egl.cpp:442-445
         const float* __restrict__ bg = p.background + pix * C;
         if ((C & 3) == 0) {
             for (int c = 0; c < C; c += 4)
@@ -289,6 +309,7 @@ __device__ __forceinline__ void shade_pixel(const RasterParams& p, const FaceRec
     edge_eval(cf, px, py, Fk);
     float b[3], cw;
     bary_eval(Fk, rec->flags, rec->inv_det, b, cw);
+    if (p.frag) p.frag[pix] = make_float4(b[0], b[1], b[2], cw);
     const float* __restrict__ cols = p.vertex_colors + (size_t)ib * p.V * C;
     const float* __restrict__ c0 = cols + (size_t)rec->vid[0] * C;
     const float* __restrict__ c1 = cols + (size_t)rec->vid[1] * C;
@@ -495,6 +516,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
         const int32_t f = s_vis[i];
         if (MODE == 1 || p.vis) p.vis[((size_t)ib * p.H + r) * p.W + x] = f;
         if (MODE == 0) shade_pixel(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
+        else if (p.frag) export_frag(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
     }
     TRACE_MARK();  // 7: stored
 #ifdef DIRT_TRACE

@@ -98,12 +98,15 @@ def _require_gpu(*tensors):
     return dev
 
 
-def _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels, flags=0, keep_state=False):
+def _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels, flags=0, keep_state=False,
+                  state_channels=0):
     """`_rasterise_module.rasterise` (dirt/rasterise_ops.py:81-85): the raw forward op, no autograd.
 
     With keep_state=True returns (pixels, state): `state` is a private workspace holding the set-up
     records and the visibility buffer, to be handed to `_op_rasterise_grad(..., state=state)` so the
-    backward pass does not render again (DIRT_FLAG_KEEP_STATE / DIRT_FLAG_REUSE_STATE)."""
+    backward pass does not render again (DIRT_FLAG_KEEP_STATE / DIRT_FLAG_REUSE_STATE).  `state_channels`
+    sizes the state for later backward calls with up to that many channels (deferred shading: the shaded
+    image need not have the G-buffer's channel count)."""
     lib = _lib.load()
     _check_forward_shapes(background, vertices, vertex_colors, faces, height, width, channels)
     dev = _require_gpu(background, vertices, vertex_colors, faces)
@@ -115,6 +118,8 @@ def _op_rasterise(background, vertices, vertex_colors, faces, height, width, cha
         if nbytes == 0:
             raise ValueError(_lib.last_error())
         if keep_state:
+            if state_channels > channels:
+                nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, state_channels)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             flags |= _lib.FLAG_KEEP_STATE
         else:
@@ -126,9 +131,15 @@ def _op_rasterise(background, vertices, vertex_colors, faces, height, width, cha
 
 
 def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, channels, flags=0, want_debug=False,
-                       state=None):
+                       state=None, state_outputs=True):
     """`_rasterise_module.rasterise_grad` (dirt/rasterise_ops.py:113-118): returns
-    (grad_background, grad_vertices, grad_vertex_colors, debug_thingy or None)."""
+    (grad_background, grad_vertices, grad_vertex_colors, debug_thingy or None).
+
+    `state`: the workspace a keep_state forward of the same vertices / faces / frame left behind; the call then
+    neither sets up nor renders again.  With state_outputs=True (one backward per forward: autograd) the vertex
+    gradients accumulate in the buffers that forward pre-cleared inside the state and the returned tensors are
+    views of it; with state_outputs=False they are fresh tensors, so a state can serve any number of backward
+    calls (deferred shading: one for the shaded image, one for the G-buffer)."""
     lib = _lib.load()
     _check_backward_shapes(vertices, faces, pixels, grad_pixels)
     if tuple(pixels.shape[1:]) != (height, width, channels):
@@ -142,7 +153,14 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
         nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, channels)
         if nbytes == 0:
             raise ValueError(_lib.last_error())
-        if state is not None:
+        if state is not None and state.numel() < nbytes:
+            state = None  # sized for fewer channels than this call has: render again
+        if state is not None and not state_outputs:
+            ws = state
+            flags |= _lib.FLAG_REUSE_STATE
+            grad_vertices = torch.empty_like(vertices)
+            grad_vertex_colors = torch.empty((B, V, channels), dtype=torch.float32, device=dev)
+        elif state is not None:
             # the gradients accumulate in the buffers the forward pass already cleared inside `state`;
             # the returned tensors are views of it
             ws = state
@@ -247,14 +265,16 @@ def rasterise_batch(background, vertices, vertex_colors, faces, height=None, wid
     return _Rasterise.apply(background, vertices, vertex_colors, faces, int(height), int(width), int(channels))
 
 
-def _rasterise_grad_multichannel(vertices, faces, pixels, d_loss_by_pixels, single_or_batch):
-    """dirt/rasterise_ops.py:132-177; one native call evaluates every channel group."""
+def _rasterise_grad_multichannel(vertices, faces, pixels, d_loss_by_pixels, single_or_batch, state=None):
+    """dirt/rasterise_ops.py:132-177; one native call evaluates every channel group.  `state`: see
+    `_op_rasterise_grad` (used with state_outputs=False, so it may be shared between calls)."""
     assert single_or_batch in ['single', 'batch']
     if single_or_batch == 'single':
         vertices, faces, pixels, d_loss_by_pixels = vertices[None], faces[None], pixels[None], d_loss_by_pixels[None]
     assert pixels.dim() == 4
     height, width, channels = (int(s) for s in pixels.shape[1:])
-    gb, gv, gvc, _ = _op_rasterise_grad(vertices, faces, pixels, d_loss_by_pixels, height, width, channels)
+    gb, gv, gvc, _ = _op_rasterise_grad(vertices, faces, pixels, d_loss_by_pixels, height, width, channels,
+                                        state=state, state_outputs=False)
     if single_or_batch == 'single':
         return {'grad_vertices': gv[0], 'grad_vertex_colors': gvc[0], 'grad_background': gb[0]}
     return {'grad_vertices': gv, 'grad_vertex_colors': gvc, 'grad_background': gb}
@@ -267,9 +287,18 @@ class _RasteriseDeferred(torch.autograd.Function):
     def forward(ctx, shader_fn, single_or_batch, n_extra, vertices, faces, attributes, background, *rest):
         shader_additional_inputs = rest[:n_extra]
         shader_params = rest[n_extra:]  # parameters closed over by shader_fn (TF's `variables`)
-        fwd = rasterise if single_or_batch == 'single' else rasterise_batch
-        with torch.no_grad():
-            gbuffer = fwd(background, vertices, attributes, faces)
+        # ONE visibility pass serves the forward and both gradient calls of the backward (the reference draws the
+        # scene once per channel group in each of the three: dirt/rasterise_ops.py:86-108,145-165)
+        batched = [t if single_or_batch == 'batch' else t[None] for t in (background, vertices, attributes, faces)]
+        height, width, channels = (int(n) for n in batched[0].shape[1:])
+        needs_grad = any(ctx.needs_input_grad[3:7])
+        if needs_grad:
+            gbuffer, state = _op_rasterise(*batched, height, width, channels, keep_state=True, state_channels=4)
+        else:
+            gbuffer, state = _op_rasterise(*batched, height, width, channels), None
+        if single_or_batch == 'single':
+            gbuffer = gbuffer[0]
+        ctx.state = state
         with torch.enable_grad():
             gbuffer_in = gbuffer.detach().requires_grad_(True)
             extra_in = [t.detach().requires_grad_(t.is_floating_point()) if isinstance(t, torch.Tensor) else t
@@ -289,7 +318,7 @@ class _RasteriseDeferred(torch.autograd.Function):
         sob = ctx.single_or_batch
         # vertex gradients from filtering the SHADED image (dirt/rasterise_ops.py:204-210)
         d_loss_by_vertices = _rasterise_grad_multichannel(
-            vertices, faces, pixels.detach(), d_loss_by_pixels.contiguous(), sob)['grad_vertices']
+            vertices, faces, pixels.detach(), d_loss_by_pixels.contiguous(), sob, ctx.state)['grad_vertices']
         # backprop through shader_fn to the G-buffer (dirt/rasterise_ops.py:212-229)
         diff_extra = [t for t in extra_in if isinstance(t, torch.Tensor) and t.requires_grad]
         diff_params = [t for t in shader_params if isinstance(t, torch.Tensor) and t.requires_grad]
@@ -300,7 +329,8 @@ class _RasteriseDeferred(torch.autograd.Function):
         extra_grads = iter(grads[1:1 + len(diff_extra)])
         param_grads = iter(grads[1 + len(diff_extra):])
         # attribute / background gradients from the G-buffer (dirt/rasterise_ops.py:231-237)
-        d_attr = _rasterise_grad_multichannel(vertices, faces, gbuffer_in.detach(), d_loss_by_gbuffer.contiguous(), sob)
+        d_attr = _rasterise_grad_multichannel(vertices, faces, gbuffer_in.detach(), d_loss_by_gbuffer.contiguous(), sob,
+                                              ctx.state)
         out = [None, None, None, d_loss_by_vertices, None, d_attr['grad_vertex_colors'], d_attr['grad_background']]
         for t in extra_in:
             out.append(next(extra_grads) if isinstance(t, torch.Tensor) and t.requires_grad else None)

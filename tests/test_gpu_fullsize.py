@@ -119,3 +119,39 @@ def test_deferred_matches_manual_composition(gpu, oracle):
     close(attrs.grad, want_a['grad_vertex_colors'][0], 'attributes')
     close(bg.grad, want_a['grad_background'][0], 'background')
     assert torch.allclose(light.grad, l2.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('shaded_channels', [3, 6])
+def test_batch_deferred_shares_one_visibility_pass(gpu, oracle, shaded_channels):
+    """rasterise_batch_deferred with the 10-channel G-buffer of samples/deferred.py:107-112: the forward's set-up
+    records + visibility serve both gradient calls (shaded image and G-buffer).  6 shaded channels exceed what
+    the state was sized for, so that call renders again -- same numbers either way."""
+    B, H, W, C = 2, 40, 56, 10
+    batch = scenes.batch_scene(300, H, W, C, [3, 4], r_lo=0.05, r_hi=0.3)
+    bg = torch.from_numpy(batch['background']).to(gpu).requires_grad_(True)
+    v = torch.from_numpy(batch['vertices']).to(gpu).requires_grad_(True)
+    attrs = torch.from_numpy(batch['vertex_colors']).to(gpu).requires_grad_(True)
+    f = torch.from_numpy(batch['faces']).to(gpu)
+    mix = torch.from_numpy(np.random.default_rng(5).uniform(0.1, 1.0, (9, shaded_channels)).astype(np.float32)).to(gpu)
+
+    def shader(gbuffer):
+        return gbuffer[..., :1] * torch.tanh(gbuffer[..., 1:] @ mix)
+
+    px = ops.rasterise_batch_deferred(bg, v, attrs, f, shader)
+    d = torch.from_numpy(np.random.default_rng(1).standard_normal((B, H, W, shaded_channels)).astype(np.float32)).to(gpu)
+    px.backward(d)
+
+    gbuf = oracle.forward(batch['background'], batch['vertices'], batch['vertex_colors'], batch['faces'])
+    gt = torch.from_numpy(gbuf).to(gpu).requires_grad_(True)
+    shaded = shader(gt)
+    assert torch.allclose(px, shaded.detach(), atol=1e-6)
+    shaded.backward(d)
+    want_v = oracle.backward(batch['vertices'], batch['faces'], shaded.detach().cpu().numpy(), d.cpu().numpy())
+    want_a = oracle.backward(batch['vertices'], batch['faces'], gbuf, gt.grad.cpu().numpy())
+
+    def close(got, want, what):
+        scale = max(1.0, float(np.abs(want).max()))
+        assert float(np.abs(got.cpu().numpy() - want).max()) <= 2e-4 * scale, what
+    close(v.grad, want_v['grad_vertices'], 'vertices')
+    close(attrs.grad, want_a['grad_vertex_colors'], 'attributes')
+    close(bg.grad, want_a['grad_background'], 'background')
