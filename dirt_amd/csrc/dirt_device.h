@@ -155,4 +155,15 @@ __device__ inline void bary_eval(const double F[3], uint32_t flags, double inv_d
     clip_w = r;
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8); give every XCD a
+// contiguous run of tiles (a band of tile rows) so neighbouring tiles, which share faces, hit the
+// same L2, and the backward pass reads a band's visibility / fragments / pixels on the XCD
+// that wrote them.  Bijective for any tile count.  Speed only; nothing depends on placement.
+__device__ __forceinline__ int xcd_tile(int b, int ntiles)
+{
+    const int x = b & 7, j = b >> 3;
+    const int q = ntiles >> 3, rem = ntiles & 7;
+    return x * q + min(x, rem) + j;
+}
+
 }  // namespace dirt

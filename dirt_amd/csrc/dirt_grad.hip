@@ -260,7 +260,7 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int iib = blockIdx.y;
-    const int tile = blockIdx.x;
+    const int tile = xcd_tile(blockIdx.x, p.tiles_x * p.tiles_y);
     const int tx0 = (tile % p.tiles_x) * GW;
     const int tr0 = (tile / p.tiles_x) * GH;
     const int H = p.H, W = p.W, C = p.C;
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
         {
             const bool col_lds = finite && slot_here != -2;
             const bool col_direct = !col_lds && face_here >= 0 && (t_here.active || slot_here == -2);
-#pragma unroll 1
+#pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float hbk = k == 0 ? fh4.x : (k == 1 ? fh4.y : fh4.z);
                 float cv[PC];
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
             // "channels" of the reference's Vec3, in its summation order) and dL/dx, dL/dy of :203-208 (the
             // group's real channels, in channel order)
             float l1x = 0.f, l1y = 0.f, dL_dx = 0.f, dL_dy = 0.f;
-#pragma unroll 1
+#pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 float sxc = 0.f, syc = 0.f;
                 if (ch < G) {
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
             const float d_yview_by_wclip = ((-.5f * height_f) * clip_y) * rcp_ww;
             const bool pos_lds = finite && slot_cur != -2;
             const bool pos_direct = !pos_lds && covered && (t_cur.active || slot_cur == -2);
-#pragma unroll 1
+#pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float cbk = k == 0 ? fc4.x : (k == 1 ? fc4.y : fc4.z);
                 const float dLx_b = dL_dx * cbk;

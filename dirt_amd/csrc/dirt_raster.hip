@@ -254,16 +254,6 @@ __device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec
     }
 }
 
-// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8); give every XCD a
-// contiguous run of tiles (a band of tile rows) so neighbouring tiles, which share faces, hit the
-// same L2.  Bijective for any tile count.  Speed only; nothing depends on placement.
-__device__ __forceinline__ int xcd_tile(int b, int ntiles)
-{
-    const int x = b & 7, j = b >> 3;
-    const int q = ntiles >> 3, rem = ntiles & 7;
-    return x * q + min(x, rem) + j;
-}
-
 // The backward pass's fragment of one pixel, (b0, b1, b2, clip_w): csrc/shaders.cpp:64-77.
 __device__ __forceinline__ void export_frag(const RasterParams& p, const FaceRec* __restrict__ recs, int ib, int x, int r,
                                             double px, double py, int32_t f)
