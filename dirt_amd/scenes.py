@@ -136,3 +136,62 @@ def cube_scene(height=256, width=256):
     colors = diffuse * 0.8 + 0.2
     return dict(background=np.zeros([height, width, 3], np.float32), vertices=clip.astype(np.float32),
                 vertex_colors=colors.astype(np.float32), faces=faces, height=height, width=width, channels=3)
+
+
+def hostile_scene(H, W, C, seed, n_small=200):
+    """Geometry that exercises every special case of the set-up / coverage / depth rules at once (the cases the
+    oracle's own tests check one by one): triangles crossing w = 0 and the near / far planes, a triangle wholly
+    behind the eye, zero-area and repeated-vertex faces, an out-of-range and a negative vertex index, a NaN and
+    an inf vertex, frame-filling triangles (the binning "big" list), coplanar duplicates (depth ties: the
+    earlier face wins), a face with enormous coordinates, and a cluster of sub-pixel triangles (more faces in
+    one tile than the gradient kernel's slot table holds)."""
+    rng = np.random.default_rng(seed)
+    verts, faces = [], []
+
+    def add(tri):  # tri: 3 x (x, y, z, w)
+        base = len(verts)
+        verts.extend(tri)
+        faces.append((base, base + 1, base + 2))
+
+    # ordinary random triangles
+    mv, mf = rand_mesh(n_small // 2, seed + 100, 0.05, 0.4)
+    for f in mf:
+        add([tuple(mv[i]) for i in f])
+    # crossing w = 0 / near plane: one or two vertices behind the eye
+    for _ in range(8):
+        tri = []
+        for k in range(3):
+            w = rng.uniform(-1.0, 2.0) if k < 2 else rng.uniform(0.5, 2.0)
+            tri.append((rng.uniform(-1.5, 1.5), rng.uniform(-1.5, 1.5), rng.uniform(-1.2, 1.2) * abs(w), w))
+        add(tri)
+    add([(0.1, 0.2, 0.0, -1.0), (0.5, -0.2, 0.0, -2.0), (-0.3, 0.1, 0.0, -0.5)])      # wholly behind the eye
+    add([(-0.5, -0.5, 1.5, 1.0), (0.5, -0.5, 1.5, 1.0), (0.0, 0.5, 1.5, 1.0)])          # beyond the far plane
+    add([(-0.9, -0.9, -1.5, 1.0), (0.9, -0.9, 0.5, 1.0), (0.0, 0.9, 0.5, 1.0)])          # cut by the near plane
+    add([(0.2, 0.2, 0.0, 1.0), (0.2, 0.2, 0.0, 1.0), (0.6, 0.1, 0.0, 1.0)])              # repeated vertex
+    add([(-0.4, -0.4, 0.0, 1.0), (0.0, 0.0, 0.0, 1.0), (0.4, 0.4, 0.0, 1.0)])            # collinear
+    add([(np.nan, 0.0, 0.0, 1.0), (0.3, 0.3, 0.0, 1.0), (0.1, 0.5, 0.0, 1.0)])           # NaN
+    add([(np.inf, 0.0, 0.0, 1.0), (0.3, -0.3, 0.0, 1.0), (0.1, -0.5, 0.0, 1.0)])         # inf
+    add([(-3.0, -3.0, 0.8, 1.0), (3.0, -3.0, 0.8, 1.0), (0.0, 3.0, 0.8, 1.0)])            # fills the frame, far
+    add([(-1.0, -1.0, 0.6, 1.0), (1.0, -1.0, 0.6, 1.0), (-1.0, 1.0, 0.6, 1.0)])           # half the frame, edges on the border
+    add([(1.0, -1.0, 0.6, 1.0), (1.0, 1.0, 0.6, 1.0), (-1.0, 1.0, 0.6, 1.0)])             # ... its watertight partner
+    add([(-1e6, -1e6, 0.7, 1.0), (1e6, -1e6, 0.7, 1.0), (0.0, 1e6, 0.7, 1.0)])            # enormous
+    t = [(-0.2, -0.6, 0.1, 1.0), (0.6, -0.5, 0.1, 1.0), (0.1, 0.1, 0.1, 1.0)]
+    add(t); add(t)                                                                        # coplanar duplicates: exact depth tie
+    # a cluster of tiny triangles inside one tile
+    cx, cy = rng.uniform(-0.5, 0.5, 2)
+    for _ in range(n_small // 2):
+        c = np.array([cx, cy]) + rng.uniform(-24.0 / W, 24.0 / W, 2)
+        r = rng.uniform(1.5, 4.0) / W
+        a0 = rng.uniform(0, 2 * np.pi)
+        z, w = rng.uniform(-0.5, 0.5), rng.uniform(1.0, 2.0)
+        add([((c[0] + r * np.cos(a0 + 2.1 * k)) * w, (c[1] + r * np.sin(a0 + 2.1 * k)) * w, z * w, w) for k in range(3)])
+    faces.append((0, 1, len(verts) + 5))   # index out of range
+    faces.append((2, -1, 3))               # negative index
+    order = rng.permutation(len(faces))    # draw order matters for ties only; shuffle everything else
+    vertices = np.asarray(verts, np.float32)
+    faces = np.asarray(faces, np.int32)[order]
+    V = vertices.shape[0]
+    return {'background': rng.uniform(0, 1, (H, W, C)).astype(np.float32), 'vertices': vertices,
+            'vertex_colors': rng.uniform(0, 1, (V, C)).astype(np.float32), 'faces': faces,
+            'grad_pixels': rng.standard_normal((H, W, C)).astype(np.float32),
+            'height': H, 'width': W, 'channels': C}

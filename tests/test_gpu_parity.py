@@ -163,3 +163,44 @@ def test_state_reuse_is_identical(gpu, oracle):
     for got in (a, b):
         _assert_grad_close(got[1].cpu().numpy(), ow['grad_vertices'], 'gv')
         _assert_grad_close(got[2].cpu().numpy(), ow['grad_vertex_colors'], 'gvc')
+
+
+@pytest.mark.parametrize('H,W,C,seed,n_small', [
+    (96, 80, 4, 1, 200),
+    (70, 50, 3, 2, 1200),   # > 64 faces in one gradient tile: the slot table overflows into the direct-atomic path
+    (33, 65, 1, 3, 400),    # 1-channel group: quirk Q1 on hostile geometry
+    (64, 64, 5, 4, 300),
+])
+def test_hostile_geometry(gpu, oracle, H, W, C, seed, n_small):
+    """Near-plane / w = 0 crossings, faces behind the eye, degenerate and invalid faces, NaN / inf vertices,
+    frame-filling and enormous triangles, exact depth ties, sub-pixel clusters: forward bit-exact, visibility
+    identical, gradients within tolerance (the cases tests/test_oracle.py pins one by one on the CPU)."""
+    s = _batched(scenes.hostile_scene(H, W, C, seed, n_small))
+    want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
+    got = _fwd_gpu(s, gpu)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    fid = ops._op_visibility(_t(s['vertices'], gpu), _t(s['faces'], gpu), H, W).cpu().numpy()
+    assert np.array_equal(fid[0], oracle.visibility(s['vertices'][0], s['faces'][0], H, W)[0])
+    for flags in (0, 1):
+        ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'], flags=flags)
+        gb, gv, gvc, _ = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
+                                                _t(s['grad_pixels'], gpu), H, W, C, flags=flags)
+        assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
+        _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
+        _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
+
+
+@pytest.mark.parametrize('H,W', [(1, 1), (1, 40), (40, 1), (2, 2), (31, 33)])
+def test_thin_frames(gpu, oracle, H, W):
+    """Frames smaller than a tile / a Scharr stencil: every tap is edge clamped (csrc/rasterise_grad_egl.cu:113-124)
+    and no pixel is interior."""
+    s = _batched(scenes.rand_scene(30, H, W, 4, 21, 0.2, 0.9))
+    want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
+    got = _fwd_gpu(s, gpu)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'])
+    gb, gv, gvc, _ = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
+                                            _t(s['grad_pixels'], gpu), H, W, 4)
+    assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
+    _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
+    _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
