@@ -16,6 +16,8 @@ FLAG_Q1_INTENDED = 1
 FLAG_KEEP_STATE = 2
 FLAG_REUSE_STATE = 4
 FLAG_PROFILE = 0x100
+FLAG_TILES_LARGE = 0x200
+FLAG_TILES_SMALL = 0x400
 
 E_INVALID_ARGUMENT = -1
 E_TOO_MANY_VERTICES = -2

@@ -189,9 +189,10 @@ dirt::GeomParams geom_params(const Carved& c, const float* vertices, const int32
     return g;
 }
 
-dirt::RasterParams raster_params(const Carved& c, const dirt::GeomParams& g, int C)
+dirt::RasterParams raster_params(const Carved& c, const dirt::GeomParams& g, int C, unsigned flags)
 {
     dirt::RasterParams p;
+    p.flags = flags;
     p.recs = c.recs; p.cells = c.cells; p.entries = c.entries; p.nchunk = g.nchunk; p.chunk_faces = g.chunk_faces;
     p.background = nullptr; p.vertex_colors = nullptr; p.pixels = nullptr; p.vis = nullptr; p.frag = nullptr;
     p.V = g.V; p.F = g.F; p.H = g.H; p.W = g.W; p.C = C;
@@ -241,7 +242,7 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
         Scope sc(prof, SLOT_GEOMETRY, stream);
         HIP_TRY(who, dirt::launch_geometry(g, stream));
     }
-    dirt::RasterParams p = raster_params(c, g, C);
+    dirt::RasterParams p = raster_params(c, g, C, flags);
     p.background = background; p.vertex_colors = vertex_colors; p.pixels = pixels;
     if (flags & DIRT_FLAG_KEEP_STATE) { p.vis = c.vis; p.frag = c.frag; }  // the records already live in the workspace
     {
@@ -275,7 +276,7 @@ int dirt_rasterise_visibility(const float* vertices, const int32_t* faces, int32
         Scope sc(prof, SLOT_GEOMETRY, stream);
         HIP_TRY(who, dirt::launch_geometry(g, stream));
     }
-    dirt::RasterParams p = raster_params(c, g, 1);
+    dirt::RasterParams p = raster_params(c, g, 1, flags);
     p.vis = face_id;
     {
         Scope sc(prof, SLOT_RASTER_VIS, stream);
@@ -327,7 +328,7 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
             Scope sc(prof, SLOT_GEOMETRY, stream);
             HIP_TRY(who, dirt::launch_geometry(g, stream));
         }
-        dirt::RasterParams rp = raster_params(c, g, C);
+        dirt::RasterParams rp = raster_params(c, g, C, flags);
         rp.vis = c.vis; rp.frag = c.frag;
         {
             Scope sc(prof, SLOT_RASTER_VIS, stream);

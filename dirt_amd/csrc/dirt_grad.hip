@@ -47,20 +47,15 @@ extern "C" void dirt_debug_set_trace_grad(void* p)
 #define GMARK() do {} while (0)
 #endif
 
-#ifndef GRAD_TILE_H
-#define GRAD_TILE_H 16
-#endif
-#ifndef GRAD_COPIES
-#define GRAD_COPIES 4
-#endif
-constexpr int GW = 32, GH = GRAD_TILE_H;  // tile = 32 x 16 pixels, one pixel per lane
-constexpr int GTHREADS = GW * GH;      // 8 waves = 4 x 2 blocks of 8 x 8 pixels
+// grad_kernel<GH, COPIES>: a tile is 32 x GH pixels, one pixel per lane, GH / 8 rows of four 8 x 8 blocks.
+//   <16, 4>  the normal shape: 8 waves, 71 KB of LDS, two workgroups per CU;
+//   <8, 2>   for small frames and dense meshes: twice the workgroups, and half the faces per tile, so the 64-slot
+//            table does not overflow where triangles are only a few pixels large; 38 KB of LDS, four workgroups per CU.
+constexpr int GW = 32;
 constexpr int PWU = GW + 4;            // staged `pixels` columns: x0-1 .. x0+34 (halo + 2 for the Q1 alias taps)
 constexpr int PW = 40;                 // ... padded: row stride = 8 (mod 32) dwords keeps an 8x8 block's reads conflict free
-constexpr int PH = GH + 2;             // staged rows: y0-1 .. y0+16
 constexpr int VWU = GW + 2;            // visibility tile with a 1-pixel halo
 constexpr int VW = 40;                 // ... padded likewise (32 (mod 64) dwords for the float4 rows)
-constexpr int COPIES = GRAD_COPIES;    // accumulator replicas per (slot, value)
 constexpr int MAX_SLOTS = 64;          // slot table capacity (LDS)
 constexpr int PC = 4;                  // channels per pass: whole channel groups that fit in 4 channels
 constexpr int NVAL = 9 + 3 * PC;       // 9 position values (3 vertices x {x,y,w}) + 3 vertices x PC colour values
@@ -138,6 +133,7 @@ struct Target {
     int copy;     // accumulator replica
 };
 
+template <int COPIES>
 __device__ __forceinline__ Target make_target(int slot, int lane)
 {
     Target t;
@@ -179,7 +175,7 @@ __device__ __forceinline__ FixScale fix_scale(float bound)
 }
 
 // N fixed-point adds (values idx0 .. idx0+N-1 of the lane's slot) under one exec mask.
-template <int N>
+template <int N, int COPIES>
 __device__ __forceinline__ void fix_add(unsigned long long* acc, const Target& t, int idx0, const float* v, float to_fix)
 {
     if (t.active) {
@@ -239,8 +235,11 @@ __device__ __forceinline__ float2 scharr_taps_wrapped(const float* __restrict__ 
     return make_float2(sx, sy);
 }
 
-__global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(GradParams p)
+template <int GH, int COPIES>
+__global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(GradParams p)
 {
+    constexpr int GTHREADS = GW * GH;  // GH / 8 x 4 waves, one 8 x 8 block each
+    constexpr int PH = GH + 2;         // staged rows: y0-1 .. y0+GH
     __shared__ float s_pix[PC][PH][PW];                              // the pass's channels of `pixels`, edge clamped
     __shared__ __align__(16) unsigned long long s_acc[MAX_SLOTS * NVAL * COPIES];  // fixed-point partial sums
     __shared__ float4 s_frag[PH][VW];                                // (b0,b1,b2,clip_w) of every pixel of the halo'd tile
@@ -297,7 +296,7 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
         return nch;
     };
     // loads of the pass's channels of the pixels tile (+halo), edge clamped (at(), :113-124): two positions per
-    // thread (PH * PWU = 648 <= 2 * 512), every load issued before any use so the tile costs one memory latency
+    // thread (PH * PWU <= 2 * GTHREADS), every load issued before any use so the tile costs one memory latency
     auto stage_load = [&](int c0, int nch, float (&v)[2][PC]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -456,7 +455,7 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
 
         const int32_t face_here = inside ? s_vis[py_l][px_l] : -1;
         const int slot_here = inside ? (int)s_slot[py_l][px_l] : -1;
-        const Target t_here = make_target(slot_here, lane);
+        const Target t_here = make_target<COPIES>(slot_here, lane);
         const int hv0 = s_vid[max(slot_here, 0)][0], hv1 = s_vid[max(slot_here, 0)][1], hv2 = s_vid[max(slot_here, 0)][2];
         const float4 fh4 = s_frag[py_l][px_l];
 
@@ -482,7 +481,7 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
 #pragma unroll
                 for (int c = 0; c < PC; ++c) cv[c] = quad_reduce(t_here, (face_here >= 0 && c < nch) ? gch[c] * hbk : 0.f);
                 if (col_lds) {
-                    fix_add<PC>(s_acc, t_here, 9 + k * PC, cv, fc.to_fix);
+                    fix_add<PC, COPIES>(s_acc, t_here, 9 + k * PC, cv, fc.to_fix);
                 } else if (col_direct) {
                     // table full, or inf / NaN in the tile: the reference's direct float atomics
 #pragma unroll
@@ -583,7 +582,7 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
             const int32_t face_cur = inside ? s_vis[cy_l][cx_l] : -1;
             const bool covered = face_cur >= 0;
             const int slot_cur = covered ? (int)s_slot[cy_l][cx_l] : -1;
-            const Target t_cur = make_target(slot_cur, lane);
+            const Target t_cur = make_target<COPIES>(slot_cur, lane);
             const float4 fc4 = s_frag[cy_l][cx_l];
             // clip-space x,y of the fragment used (:210-215 sums b_k * vertex_k.xy; perspective-correct
             // barycentrics make that sum the fragment's own clip position = its NDC position times clip_w,
@@ -612,7 +611,7 @@ __global__ __launch_bounds__(GTHREADS, GRAD_WAVES_PER_SIMD) void grad_kernel(Gra
                 pv[1] = quad_reduce(t_cur, covered ? dLy_b * d_yview_by_yclip : 0.f);
                 pv[2] = quad_reduce(t_cur, covered ? gw1 + gw2 : 0.f);
                 if (pos_lds) {
-                    fix_add<3>(s_acc, t_cur, 3 * k, pv, fp.to_fix);
+                    fix_add<3, COPIES>(s_acc, t_cur, 3 * k, pv, fp.to_fix);
                 } else if (pos_direct) {
                     float* gv = grad_vertices + (size_t)recs[face_cur].vid[k] * 4;
                     atomicAdd(gv + 0, pv[0]);
@@ -668,11 +667,21 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     if (p_in.B == 0) return hipSuccess;
     GradParams p = p_in;
     p.tiles_x = (p.W + GW - 1) / GW;
-    p.tiles_y = (p.H + GH - 1) / GH;
+    // 32 x 16 tiles unless the frame is small (fewer than two workgroups per CU) or the mesh is dense (the expected
+    // number of faces in a halo'd tile approaches the 64 slots of the table): then 32 x 8
+    const double faces_per_tile = (double)p.F * (34.0 * 18.0) / ((double)p.H * (double)p.W);
+    const long long tiles16 = (long long)p.tiles_x * ((p.H + 15) / 16) * p.B;
+    int gh = (tiles16 < 512 || faces_per_tile > 40.0) ? 8 : 16;
+    if (p.flags & DIRT_FLAG_TILES_LARGE) gh = 16;
+    if (p.flags & DIRT_FLAG_TILES_SMALL) gh = 8;
+    p.tiles_y = (p.H + gh - 1) / gh;
     p.nslots = MAX_SLOTS;
     p.pixels_aligned16 = ((reinterpret_cast<uintptr_t>(p.pixels) | reinterpret_cast<uintptr_t>(p.grad_background)) & 15u) == 0 ? 1 : 0;
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.B);
-    hipLaunchKernelGGL(grad_kernel, grid, dim3(GTHREADS), 0, stream, p);
+    if (gh == 16)
+        hipLaunchKernelGGL((grad_kernel<16, 4>), grid, dim3(GW * 16), 0, stream, p);
+    else
+        hipLaunchKernelGGL((grad_kernel<8, 2>), grid, dim3(GW * 8), 0, stream, p);
     return hipGetLastError();
 }
 

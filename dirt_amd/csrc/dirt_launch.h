@@ -56,6 +56,7 @@ struct RasterParams {
     float4* frag;                // [B,H,W] (b0,b1,b2,clip_w) of the front-most fragment, exported with vis for the backward pass; or nullptr
     int V, F, H, W, C;
     BinGrid grid;
+    unsigned flags;              // DIRT_FLAG_TILES_*
     int tiles_x, tiles_y;        // filled by launch_raster
 };
 

@@ -7,7 +7,7 @@
 //   * upload_background / download_pixels           (csrc/rasterise_egl.cu:10-38,65-91): there is no
 //     RGBA32F atlas; tiles read `background` and write `pixels` in place, top row first.
 //
-// Structure of raster_kernel (one 256-thread workgroup = one 32x32 pixel tile of one scene = 4x4
+// Structure of raster_kernel<MODE, NB = 2> (one 256-thread workgroup = one 32x32 pixel tile of one scene = 4x4
 // blocks of 8x8 pixels; each of its 4 waves owns a 16x16 region = 2x2 blocks, 4 pixels per lane, so
 // that one record fetch serves 256 pixels):
 //   scan   : the threads walk column `bin` of the chunk x bin directory (binary search over the run
@@ -24,6 +24,7 @@
 //            interpolated once, and the HWC pixel is written (background copied where uncovered).
 #include "dirt_device.h"
 #include "dirt_launch.h"
+#include "../../include/dirt_hip.h"
 
 namespace dirt {
 
@@ -152,9 +153,10 @@ __global__ __launch_bounds__(256) void setup_kernel(GeomParams g)
     }
 }
 
-constexpr int TILE_W = 32;        // tile = 32 x 32 pixels = 4 x 4 blocks
-constexpr int TILE_H = 32;
-constexpr int RTHREADS = 256;     // 4 waves; each owns a 16 x 16 region = 2 x 2 blocks, 4 pixels per lane
+// A tile is 2 x 2 wave regions; a wave region is NB x NB blocks of 8 x 8 pixels (NB * NB pixels per lane).
+// NB = 2 (32 x 32 tiles, one record fetch serves 256 pixels) is the normal shape; NB = 1 (16 x 16 tiles) gives four
+// times as many workgroups for small frames, where 32 x 32 tiles would leave most of the 1024 SIMDs idle.
+constexpr int RTHREADS = 256;     // 4 waves
 constexpr int LIST_CAP = 2048;    // bin entries scanned (and at most listed) per round
 
 // What the coverage / depth loop reads per candidate: built once per (tile, candidate) by one lane when the
@@ -233,23 +235,24 @@ __device__ __forceinline__ void raster_block(const TileRec& t, const FaceRec* __
     fbest = wins ? t.face : fbest;
 }
 
-// One candidate against the wave's 2 x 2 blocks; `m4` (wave-uniform) says which blocks its box touches.
-__device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec* __restrict__ recs, uint32_t m4, const float dx[2],
-                                                 const float dy[2], const double px[2], const double py[2], uint32_t zbest[4],
-                                                 int32_t fbest[4])
+// One candidate against the wave's NB x NB blocks; `m4` (wave-uniform) says which blocks its box touches.
+template <int NB>
+__device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec* __restrict__ recs, uint32_t m4, const float* dx,
+                                                 const float* dy, const double* px, const double* py, uint32_t* zbest,
+                                                 int32_t* fbest)
 {
 #pragma unroll
-    for (int by = 0; by < 2; ++by) {
-        if ((m4 >> (2 * by)) & 3u) {
+    for (int by = 0; by < NB; ++by) {
+        if ((m4 >> (NB * by)) & ((1u << NB) - 1u)) {
             float trow[3];
             trow[0] = fmaf(t.b[0], dy[by], t.c[0]);
             trow[1] = fmaf(t.b[1], dy[by], t.c[1]);
             trow[2] = fmaf(t.b[2], dy[by], t.c[2]);
             const double qrow = fma(t.zp[1], py[by], t.zp[2]);
 #pragma unroll
-            for (int bx = 0; bx < 2; ++bx)
-                if ((m4 >> (2 * by + bx)) & 1u)
-                    raster_block(t, recs, dx[bx], trow, px[bx], py[by], qrow, zbest[2 * by + bx], fbest[2 * by + bx]);
+            for (int bx = 0; bx < NB; ++bx)
+                if ((m4 >> (NB * by + bx)) & 1u)
+                    raster_block(t, recs, dx[bx], trow, px[bx], py[by], qrow, zbest[NB * by + bx], fbest[NB * by + bx]);
         }
     }
 }
@@ -321,9 +324,11 @@ __device__ __forceinline__ void shade_pixel(const RasterParams& p, const FaceRec
     }
 }
 
-template <int MODE>
+template <int MODE, int NB>
 __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
 {
+    constexpr int TILE_W = 16 * NB, TILE_H = 16 * NB;  // pixels
+    constexpr int BT = 2 * NB;                         // blocks per tile side: block (bx, by) = mask bit BT * by + bx
     __shared__ int32_t s_face[LIST_CAP];
     __shared__ uint16_t s_mask[LIST_CAP];  // bit (4*by + bx): the face's box touches block (bx, by) of the tile
     __shared__ uint32_t s_count;
@@ -393,23 +398,26 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
     __syncthreads();
     const int n_all = (int)s_pre[nruns];
 
-    // this wave's 16 x 16 region (blocks 2wx..2wx+1, 2wy..2wy+1 of the tile) and this lane's 4 pixels
+    // this wave's region (blocks NB*wx .. NB*wx + NB-1, NB*wy .. of the tile) and this lane's NB x NB pixels
     const int wx = wave & 1, wy = wave >> 1;
-    const int x0 = tx0 + wx * 16 + (lane & 7);
-    const int r0 = tr0 + wy * 16 + (lane >> 3);
-    const double px[2] = {(double)x0 + 0.5, (double)(x0 + 8) + 0.5};
-    const double py[2] = {(double)(p.H - 1 - r0) + 0.5, (double)(p.H - 1 - (r0 + 8)) + 0.5};
+    const int x0 = tx0 + wx * (8 * NB) + (lane & 7);
+    const int r0 = tr0 + wy * (8 * NB) + (lane >> 3);
+    double px[NB], py[NB];
     // tile-local sample coordinates (exact small integers): dx = px - (tx0 + 0.5), dy = py - py(tile's top row)
-    const float dxl[2] = {(float)(x0 - tx0), (float)(x0 + 8 - tx0)};
-    const float dyl[2] = {(float)(tr0 - r0), (float)(tr0 - (r0 + 8))};
-    const float wf = (float)p.W, hf = (float)p.H;
-    // the wave's four block bits inside a 16-bit tile mask, gathered into 4 bits (2*by + bx)
-    const int sh0 = (2 * wy) * 4 + 2 * wx, sh1 = (2 * wy + 1) * 4 + 2 * wx;
-
-    uint32_t zbest[4];
-    int32_t fbest[4];
+    float dxl[NB], dyl[NB];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { zbest[k] = Z24_CLEAR; fbest[k] = -1; }  // -1: a tie with the cleared depth never wins
+    for (int k = 0; k < NB; ++k) {
+        px[k] = (double)(x0 + 8 * k) + 0.5;
+        py[k] = (double)(p.H - 1 - (r0 + 8 * k)) + 0.5;
+        dxl[k] = (float)(x0 + 8 * k - tx0);
+        dyl[k] = (float)(tr0 - (r0 + 8 * k));
+    }
+    const float wf = (float)p.W, hf = (float)p.H;
+
+    uint32_t zbest[NB * NB];
+    int32_t fbest[NB * NB];
+#pragma unroll
+    for (int k = 0; k < NB * NB; ++k) { zbest[k] = Z24_CLEAR; fbest[k] = -1; }  // -1: a tie with the cleared depth never wins
 
     TRACE_MARK();  // 1: directory loaded
     for (int round = 0; round < n_all; round += LIST_CAP) {
@@ -442,9 +450,9 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
                     const uint32_t slot = off + __popcll(m & ((1ull << lane) - 1ull));
                     const int bx0 = max(en.box.i_min - tx0, 0) >> 3, bx1 = min(en.box.i_max - tx0, TILE_W - 1) >> 3;
                     const int by0 = max(en.box.r_min - tr0, 0) >> 3, by1 = min(en.box.r_max - tr0, TILE_H - 1) >> 3;
-                    const uint32_t rowbits = ((2u << bx1) - (1u << bx0)) & 0xFu;
+                    const uint32_t rowbits = ((2u << bx1) - (1u << bx0)) & ((1u << BT) - 1u);
                     uint32_t mask = 0;
-                    for (int by = by0; by <= by1; ++by) mask |= rowbits << (4 * by);
+                    for (int by = by0; by <= by1; ++by) mask |= rowbits << (BT * by);
                     s_face[slot] = en.face;
                     s_mask[slot] = (uint16_t)mask;
                 }
@@ -471,7 +479,10 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
             uint32_t mym4 = 0;
             if (idx < n) {
                 const uint32_t mk = s_mask[idx];
-                mym4 = ((mk >> sh0) & 3u) | (((mk >> sh1) & 3u) << 2);
+                // the wave's block bits inside the tile mask, gathered into NB * NB bits (NB * by + bx)
+#pragma unroll
+                for (int by = 0; by < NB; ++by)
+                    mym4 |= ((mk >> ((NB * wy + by) * BT + NB * wx)) & ((1u << NB) - 1u)) << (NB * by);
             }
             unsigned long long m = __ballot(mym4 != 0);
             while (m) {
@@ -479,7 +490,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
                 m &= m - 1;
                 const uint32_t m4 = (uint32_t)__builtin_amdgcn_readlane((int)mym4, k);
                 const TileRec t = s_rec[k];
-                raster_candidate(t, recs, m4, dxl, dyl, px, py, zbest, fbest);
+                raster_candidate<NB>(t, recs, m4, dxl, dyl, px, py, zbest, fbest);
                 TRACE_CNT();
             }
             TRACE_ACC(2);
@@ -494,14 +505,14 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
     //      threads walk the tile row-major (32 consecutive pixels of a row per half-wave: coalesced HWC
     //      stores) to export visibility and / or shade ----
 #pragma unroll
-    for (int by = 0; by < 2; ++by)
+    for (int by = 0; by < NB; ++by)
 #pragma unroll
-        for (int bx = 0; bx < 2; ++bx)
-            s_vis[(wy * 16 + by * 8 + (lane >> 3)) * TILE_W + wx * 16 + bx * 8 + (lane & 7)] = fbest[2 * by + bx];
+        for (int bx = 0; bx < NB; ++bx)
+            s_vis[(wy * (8 * NB) + by * 8 + (lane >> 3)) * TILE_W + wx * (8 * NB) + bx * 8 + (lane & 7)] = fbest[NB * by + bx];
     __syncthreads();
 #pragma unroll 1
     for (int i = tid; i < TILE_W * TILE_H; i += RTHREADS) {
-        const int x = tx0 + (i & (TILE_W - 1)), r = tr0 + (i >> 5);
+        const int x = tx0 + (i & (TILE_W - 1)), r = tr0 + i / TILE_W;
         if (r >= p.H || x >= p.W) continue;
         const int32_t f = s_vis[i];
         if (MODE == 1 || p.vis) p.vis[((size_t)ib * p.H + r) * p.W + x] = f;
@@ -560,7 +571,7 @@ void chunking(int F, int& nchunk, int& chunk_faces)
 BinGrid make_bin_grid(int H, int W)
 {
     BinGrid g;
-    g.shift = 7;
+    g.shift = 5;  // bins of >= 32 pixels: a raster tile (32 or 16 pixels) never straddles two bins
     while (((W + (1 << g.shift) - 1) >> g.shift) * ((H + (1 << g.shift) - 1) >> g.shift) > MAX_BINS) ++g.shift;
     g.bins_x = (W + (1 << g.shift) - 1) >> g.shift;
     g.bins_y = (H + (1 << g.shift) - 1) >> g.shift;
@@ -571,13 +582,25 @@ hipError_t launch_raster(const RasterParams& p_in, int B, bool visibility_only, 
 {
     if (B == 0) return hipSuccess;
     RasterParams p = p_in;
-    p.tiles_x = (p.W + TILE_W - 1) / TILE_W;
-    p.tiles_y = (p.H + TILE_H - 1) / TILE_H;
+    // 32 x 32 tiles unless that leaves the chip mostly idle (fewer than two workgroups per CU): then 16 x 16
+    const long long tiles32 = (long long)((p.W + 31) / 32) * ((p.H + 31) / 32) * B;
+    int tile = tiles32 >= 512 ? 32 : 16;
+    if (p.flags & DIRT_FLAG_TILES_LARGE) tile = 32;
+    if (p.flags & DIRT_FLAG_TILES_SMALL) tile = 16;
+    p.tiles_x = (p.W + tile - 1) / tile;
+    p.tiles_y = (p.H + tile - 1) / tile;
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)B);
-    if (visibility_only)
-        hipLaunchKernelGGL(raster_kernel<1>, grid, dim3(RTHREADS), 0, stream, p);
-    else
-        hipLaunchKernelGGL(raster_kernel<0>, grid, dim3(RTHREADS), 0, stream, p);
+    if (tile == 32) {
+        if (visibility_only)
+            hipLaunchKernelGGL((raster_kernel<1, 2>), grid, dim3(RTHREADS), 0, stream, p);
+        else
+            hipLaunchKernelGGL((raster_kernel<0, 2>), grid, dim3(RTHREADS), 0, stream, p);
+    } else {
+        if (visibility_only)
+            hipLaunchKernelGGL((raster_kernel<1, 1>), grid, dim3(RTHREADS), 0, stream, p);
+        else
+            hipLaunchKernelGGL((raster_kernel<0, 1>), grid, dim3(RTHREADS), 0, stream, p);
+    }
     return hipGetLastError();
 }
 

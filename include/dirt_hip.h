@@ -58,6 +58,10 @@ extern "C" {
                                     in separate outputs").  The state is caller-owned memory; the library
                                     stays stateless.  Results are identical with or without the flag. */
 
+#define DIRT_FLAG_TILES_LARGE 0x200u /* pin the kernels' tile shape instead of letting the library choose it from the
+                                       frame size and the face density (32x32 raster / 32x16 gradient tiles) ... */
+#define DIRT_FLAG_TILES_SMALL 0x400u /* ... or 16x16 / 32x8 tiles.  Results do not depend on the shape (pixels and
+                                       visibility bit for bit; gradients up to float-atomic order); for tests. */
 #define DIRT_FLAG_PROFILE 0x100u /* record a HIP-event pair around every kernel this call launches (on the
                                     call's stream); read the totals with dirt_profile_read.  Replaces the
                                     reference's compile-time TIME_SECTIONS wall-clock prints

@@ -155,3 +155,29 @@ def test_batch_deferred_shares_one_visibility_pass(gpu, oracle, shaded_channels)
     close(v.grad, want_v['grad_vertices'], 'vertices')
     close(attrs.grad, want_a['grad_vertex_colors'], 'attributes')
     close(bg.grad, want_a['grad_background'], 'background')
+
+
+def test_step_is_capturable_in_a_hip_graph(gpu):
+    """The library only enqueues kernels on the caller's stream (no allocation, no synchronisation, no
+    library-owned device state), so a forward + backward step can be captured once in a hipGraph and replayed:
+    pixels identical, gradients equal up to the order of the float atomics."""
+    F, H, W, C, seed, r_lo, r_hi = scenes.CONFIGS['K3']
+    s = scenes.rand_scene(F, H, W, C, seed, r_lo, r_hi)
+    bg, v, vc, f, g = (torch.from_numpy(s[k][None]).to(gpu) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels'))
+
+    def step():
+        px, state = ops._op_rasterise(bg, v, vc, f, H, W, C, keep_state=True)
+        return (px,) + ops._op_rasterise_grad(v, f, px, g, H, W, C, state=state)[:3]
+
+    ref = [t.clone() for t in step()]
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    for a, b in zip(out[2:], ref[2:]):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 1e-4 * scale

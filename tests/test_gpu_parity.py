@@ -21,9 +21,14 @@ def _batched(s):
     return {k: (v[None] if isinstance(v, np.ndarray) and v.ndim in (2, 3) and k != 'x' else v) for k, v in s.items()}
 
 
-def _fwd_gpu(s, dev):
+def _fwd_gpu(s, dev, flags=0):
     return ops._op_rasterise(_t(s['background'], dev), _t(s['vertices'], dev), _t(s['vertex_colors'], dev),
-                             _t(s['faces'], dev), s['height'], s['width'], s['channels']).cpu().numpy()
+                             _t(s['faces'], dev), s['height'], s['width'], s['channels'], flags=flags).cpu().numpy()
+
+
+# The library picks the kernels' tile shape from the frame size and the face density; small test frames would
+# only ever see the small shape, so the parity tests pin each shape in turn (DIRT_FLAG_TILES_*).
+TILE_SHAPES = [pytest.param(0, id='auto'), pytest.param(0x200, id='large-tiles'), pytest.param(0x400, id='small-tiles')]
 
 
 def _assert_grad_close(got, want, what):
@@ -49,10 +54,11 @@ def test_square_all_pixels_agree(gpu):
     ('dense', 3000, 256, 256, 4, 8, 0.005, 0.04, False),  # more faces than one scan round lists
     ('shared', 2000, 200, 120, 3, 9, 0.0, 0.0, True),
 ])
-def test_forward_bit_exact_and_gradients(gpu, oracle, name, F, H, W, C, seed, rlo, rhi, shared):
+@pytest.mark.parametrize('tiles', TILE_SHAPES)
+def test_forward_bit_exact_and_gradients(gpu, oracle, name, F, H, W, C, seed, rlo, rhi, shared, tiles):
     s = _batched(scenes.rand_scene(F, H, W, C, seed, rlo, rhi, shared))
     want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
-    got = _fwd_gpu(s, gpu)
+    got = _fwd_gpu(s, gpu, tiles)
     assert got.shape == want.shape
     nbad = int(np.sum(got.view(np.uint32) != want.view(np.uint32)))
     assert nbad == 0, '%s: %d of %d pixel values differ from the oracle' % (name, nbad, got.size)
@@ -60,7 +66,7 @@ def test_forward_bit_exact_and_gradients(gpu, oracle, name, F, H, W, C, seed, rl
     for flags in (0, 1):
         ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'], flags=flags, want_debug=True)
         gb, gv, gvc, dbg = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
-                                                  _t(s['grad_pixels'], gpu), H, W, C, flags=flags, want_debug=True)
+                                                  _t(s['grad_pixels'], gpu), H, W, C, flags=flags | tiles, want_debug=True)
         assert np.array_equal(gb.cpu().numpy(), ow['grad_background']), name
         _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], name + ' grad_vertex_colors')
         _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], name + ' grad_vertices')
@@ -122,7 +128,8 @@ def test_empty_inputs(gpu):
     assert torch.equal(out, bg[:1])
 
 
-def test_golden_fixtures_on_gpu(gpu):
+@pytest.mark.parametrize('tiles', TILE_SHAPES[1:])
+def test_golden_fixtures_on_gpu(gpu, tiles):
     """The committed fixtures (tests/golden/make_golden.py) reproduced by the HIP path alone."""
     import glob
     import os
@@ -136,28 +143,29 @@ def test_golden_fixtures_on_gpu(gpu):
         s = make_inputs(CASES[name])
         B, H, W, C = s['background'].shape
         s.update(height=H, width=W, channels=C)
-        got = _fwd_gpu(s, gpu)
+        got = _fwd_gpu(s, gpu, tiles)
         assert np.array_equal(got.view(np.uint32), z['pixels'].view(np.uint32)), name
         vis = ops._op_visibility(_t(s['vertices'], gpu), _t(s['faces'], gpu), H, W).cpu().numpy()
         assert np.array_equal(vis, z['face_id']), name
         gb, gv, gvc, _ = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(z['pixels'], gpu),
-                                                _t(s['grad_pixels'], gpu), H, W, C)
+                                                _t(s['grad_pixels'], gpu), H, W, C, flags=tiles)
         assert np.array_equal(gb.cpu().numpy(), z['grad_background']), name
         _assert_grad_close(gv.cpu().numpy(), z['grad_vertices'], name + ' gv')
         _assert_grad_close(gvc.cpu().numpy(), z['grad_vertex_colors'], name + ' gvc')
 
 
-def test_state_reuse_is_identical(gpu, oracle):
+@pytest.mark.parametrize('tiles', TILE_SHAPES[1:])
+def test_state_reuse_is_identical(gpu, oracle, tiles):
     """DIRT_FLAG_KEEP_STATE / DIRT_FLAG_REUSE_STATE: the backward pass fed with the forward's records +
     visibility gives the same result as the stateless one that renders again."""
     s = _batched(scenes.rand_scene(600, 100, 140, 4, 41, 0.02, 0.2))
     args = [_t(s[k], gpu) for k in ('background', 'vertices', 'vertex_colors', 'faces')]
-    px, state = ops._op_rasterise(*args, 100, 140, 4, keep_state=True)
-    px2 = ops._op_rasterise(*args, 100, 140, 4)
+    px, state = ops._op_rasterise(*args, 100, 140, 4, keep_state=True, flags=tiles)
+    px2 = ops._op_rasterise(*args, 100, 140, 4, flags=tiles)
     assert torch.equal(px, px2)
     g = _t(s['grad_pixels'], gpu)
-    a = ops._op_rasterise_grad(args[1], args[3], px, g, 100, 140, 4, state=state)
-    b = ops._op_rasterise_grad(args[1], args[3], px, g, 100, 140, 4)
+    a = ops._op_rasterise_grad(args[1], args[3], px, g, 100, 140, 4, state=state, flags=tiles)
+    b = ops._op_rasterise_grad(args[1], args[3], px, g, 100, 140, 4, flags=tiles)
     assert torch.equal(a[0], b[0])
     ow = oracle.backward(s['vertices'], s['faces'], px.cpu().numpy(), s['grad_pixels'])
     for got in (a, b):
@@ -171,20 +179,21 @@ def test_state_reuse_is_identical(gpu, oracle):
     (33, 65, 1, 3, 400),    # 1-channel group: quirk Q1 on hostile geometry
     (64, 64, 5, 4, 300),
 ])
-def test_hostile_geometry(gpu, oracle, H, W, C, seed, n_small):
+@pytest.mark.parametrize('tiles', TILE_SHAPES[1:])
+def test_hostile_geometry(gpu, oracle, H, W, C, seed, n_small, tiles):
     """Near-plane / w = 0 crossings, faces behind the eye, degenerate and invalid faces, NaN / inf vertices,
     frame-filling and enormous triangles, exact depth ties, sub-pixel clusters: forward bit-exact, visibility
     identical, gradients within tolerance (the cases tests/test_oracle.py pins one by one on the CPU)."""
     s = _batched(scenes.hostile_scene(H, W, C, seed, n_small))
     want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
-    got = _fwd_gpu(s, gpu)
+    got = _fwd_gpu(s, gpu, tiles)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     fid = ops._op_visibility(_t(s['vertices'], gpu), _t(s['faces'], gpu), H, W).cpu().numpy()
     assert np.array_equal(fid[0], oracle.visibility(s['vertices'][0], s['faces'][0], H, W)[0])
     for flags in (0, 1):
         ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'], flags=flags)
         gb, gv, gvc, _ = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
-                                                _t(s['grad_pixels'], gpu), H, W, C, flags=flags)
+                                                _t(s['grad_pixels'], gpu), H, W, C, flags=flags | tiles)
         assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
         _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
         _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
