@@ -2,3 +2,4 @@
 `rasterise`, `rasterise_batch`, `rasterise_deferred`, `rasterise_batch_deferred` (dirt/__init__.py:2)."""
 from .rasterise_ops import rasterise, rasterise_batch, rasterise_deferred, rasterise_batch_deferred  # noqa: F401
 from . import rasterise_ops  # noqa: F401
+from . import matrices, lighting, projection  # noqa: F401  (dirt.matrices, dirt.lighting, dirt.projection)

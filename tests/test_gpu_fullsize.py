@@ -181,3 +181,35 @@ def test_step_is_capturable_in_a_hip_graph(gpu):
     for a, b in zip(out[2:], ref[2:]):
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 1e-4 * scale
+
+
+def test_simple_sample_end_to_end(gpu, oracle):
+    """samples/simple.py:34-78 through dirt_amd.matrices / lighting / rasterise on the GPU: the image equals the
+    oracle's on the very clip-space vertices the helpers produced, and a loss on it reaches the rotation
+    parameter through the rasteriser's gradient and the matrix helpers."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('example_simple', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'simple.py'))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    from dirt_amd import lighting, matrices
+    rotation = torch.tensor([0., 0.5, 0.], device=gpu, requires_grad=True)
+    px = ex.render(rotation, gpu)
+    assert px.shape == (480, 640, 3)
+    # rebuild the same inputs to hand them to the oracle
+    vertices, faces = ex.build_cube()
+    v, f = lighting.split_vertices_by_face(torch.tensor(vertices, dtype=torch.float32, device=gpu), torch.tensor(faces, dtype=torch.int32, device=gpu))
+    colors = torch.ones_like(v)
+    v = torch.cat([v, torch.ones_like(v[:, -1:])], dim=1)
+    world = v @ matrices.rodrigues(rotation.detach())
+    normals = lighting.vertex_normals_pre_split(world, f)
+    view = matrices.compose(matrices.translation(torch.tensor([0., -1.5, -3.5], device=gpu)), matrices.rodrigues(torch.tensor([-0.3, 0., 0.], device=gpu)))
+    clip = (world @ view) @ matrices.perspective_projection(near=0.1, far=20., right=0.1, aspect=480. / 640.).to(gpu)
+    lit = lighting.diffuse_directional(normals, colors, light_direction=torch.tensor([1., 0., 0.], device=gpu), light_color=torch.tensor([1., 1., 1.], device=gpu)) * 0.8 + colors * 0.2
+    want = oracle.forward(np.zeros((1, 480, 640, 3), np.float32), clip.cpu().numpy()[None], lit.cpu().numpy()[None], f.cpu().numpy()[None])
+    assert np.array_equal(px.detach().cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+    assert 0.1 < float((px.detach().sum(-1) > 0).float().mean()) < 0.6  # the cube covers a good part of the frame
+    target = ex.render(torch.tensor([0., 0.35, 0.], device=gpu), gpu).detach()
+    ((px - target) ** 2).sum().backward()
+    assert torch.isfinite(rotation.grad).all() and float(rotation.grad.abs().max()) > 0
+    assert float(rotation.grad[1]) > 0  # turning back towards the target (smaller angle) lowers the loss
