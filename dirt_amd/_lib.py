@@ -18,6 +18,7 @@ FLAG_REUSE_STATE = 4
 FLAG_PROFILE = 0x100
 FLAG_TILES_LARGE = 0x200
 FLAG_TILES_SMALL = 0x400
+FLAG_SHARED_FACES = 0x800
 
 E_INVALID_ARGUMENT = -1
 E_TOO_MANY_VERTICES = -2

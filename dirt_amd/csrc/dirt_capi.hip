@@ -177,9 +177,10 @@ Carved carved(void* workspace, const Workspace& w)
 }
 
 dirt::GeomParams geom_params(const Carved& c, const float* vertices, const int32_t* faces, int B, int V, int F, int H,
-                             int W)
+                             int W, unsigned flags)
 {
     dirt::GeomParams g;
+    g.shared_faces = (flags & DIRT_FLAG_SHARED_FACES) ? 1 : 0;
     g.vertices = vertices; g.faces = faces; g.recs = c.recs; g.boxes = c.boxes; g.cells = c.cells;
     g.entries = c.entries;
     dirt::chunking(F, g.nchunk, g.chunk_faces);
@@ -233,7 +234,7 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const Carved c = carved(workspace, w);
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
-    dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W);
+    dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
     if (flags & DIRT_FLAG_KEEP_STATE) {  // pre-clear the backward pass's accumulators (dirt_state_grad_buffers)
         g.zero_b = c.gv;  g.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
         g.zero_c = c.gvc; g.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
@@ -271,7 +272,7 @@ int dirt_rasterise_visibility(const float* vertices, const int32_t* faces, int32
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const Carved c = carved(workspace, w);
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
-    const dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W);
+    const dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
     {
         Scope sc(prof, SLOT_GEOMETRY, stream);
         HIP_TRY(who, dirt::launch_geometry(g, stream));
@@ -321,7 +322,7 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
                                            sizeof(float) * (size_t)B * V * C, stream));
         }
     } else {
-        dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W);
+        dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
         g.zero_b = grad_vertices;      g.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
         g.zero_c = grad_vertex_colors; g.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
         {

@@ -30,7 +30,8 @@ struct BinCell {
 
 struct GeomParams {
     const float* vertices;  // [B,V,4]
-    const int32_t* faces;   // [B,F,3]
+    const int32_t* faces;   // [B,F,3], or [F,3] when shared_faces
+    int shared_faces;       // one topology for every scene of the batch (DIRT_FLAG_SHARED_FACES)
     FaceRec* recs;          // [B*F]
     FaceBox* boxes;         // [B*F]
     BinCell* cells;         // [B][nchunk][MAX_BINS + 1] chunk x bin directory

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void setup_kernel(GeomParams g)
         const size_t n = (size_t)ib * g.F + f;
         FaceRec rec;
         FaceBox box;
-        if (setup_face(verts, g.V, g.faces + n * 3, g.H, g.W, rec, box)) {
+        if (setup_face(verts, g.V, g.faces + (g.shared_faces ? (size_t)f : n) * 3, g.H, g.W, rec, box)) {
             g.recs[n] = rec;
             int bx0, bx1, by0, by1;
             if (bin_range(box, g.grid, bx0, bx1, by0, by1)) {

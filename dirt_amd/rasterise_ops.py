@@ -62,10 +62,11 @@ def _check_forward_shapes(background, vertices, vertex_colors, faces, height, wi
         raise ValueError('Rasterise expects vertices to be 3D, and vertices.shape[2] == 4')
     if not (vertex_colors.dim() == 3 and vertex_colors.shape[1] == vertices.shape[1] and vertex_colors.shape[2] == channels):
         raise ValueError('Rasterise expects vertex_colors to be 3D, and vertex_colors.shape == [None, vertices.shape[1], channels]')
-    if not (faces.dim() == 3 and faces.shape[2] == 3):
+    if not ((faces.dim() == 3 or faces.dim() == 2) and faces.shape[-1] == 3):  # 2D: one topology shared by the batch
         raise ValueError('Rasterise expects faces to be 3D, and faces.shape[2] == 3')
     batch_size = vertices.shape[0]
-    if not (background.shape[0] == batch_size and vertex_colors.shape[0] == batch_size and faces.shape[0] == batch_size):
+    if not (background.shape[0] == batch_size and vertex_colors.shape[0] == batch_size
+            and (faces.dim() == 2 or faces.shape[0] == batch_size)):
         raise ValueError('Rasterise expects all arguments to have same leading (batch) dimension')
 
 
@@ -73,14 +74,15 @@ def _check_backward_shapes(vertices, faces, pixels, grad_pixels):
     # OP_REQUIRES conditions of csrc/rasterise_grad_egl.cpp:349-377
     if not (vertices.dim() == 3 and vertices.shape[2] == 4):
         raise ValueError('RasteriseGrad expects vertices to be 3D, and vertices.shape[2] == 4')
-    if not (faces.dim() == 3 and faces.shape[2] == 3):
+    if not ((faces.dim() == 3 or faces.dim() == 2) and faces.shape[-1] == 3):  # 2D: one topology shared by the batch
         raise ValueError('RasteriseGrad expects faces to be 3D, and faces.shape[2] == 3')
     if pixels.dim() != 4:
         raise ValueError('RasteriseGrad expects pixels to be 4D, and pixels.shape == [None, height, width, channels]')
     if grad_pixels.dim() != 4 or grad_pixels.shape[1:] != pixels.shape[1:]:
         raise ValueError('RasteriseGrad expects grad_pixels to be 4D, and grad_pixels.shape == [None, height, width, channels]')
     batch_size = vertices.shape[0]
-    if not (faces.shape[0] == batch_size and pixels.shape[0] == batch_size and grad_pixels.shape[0] == batch_size):
+    if not ((faces.dim() == 2 or faces.shape[0] == batch_size) and pixels.shape[0] == batch_size
+            and grad_pixels.shape[0] == batch_size):
         raise ValueError('RasteriseGrad expects all arguments to have same leading (batch) dimension')
 
 
@@ -111,7 +113,9 @@ def _op_rasterise(background, vertices, vertex_colors, faces, height, width, cha
     _check_forward_shapes(background, vertices, vertex_colors, faces, height, width, channels)
     dev = _require_gpu(background, vertices, vertex_colors, faces)
     background, vertices, vertex_colors, faces = (t.contiguous() for t in (background, vertices, vertex_colors, faces))
-    B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[1]
+    B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[-2]
+    if faces.dim() == 2:
+        flags |= _lib.FLAG_SHARED_FACES
     pixels = torch.empty_like(background)
     with torch.cuda.device(dev):
         nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, channels)
@@ -146,7 +150,9 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
         raise ValueError('RasteriseGrad expects pixels to be 4D, and pixels.shape == [None, height, width, channels]')
     dev = _require_gpu(vertices, faces, pixels, grad_pixels)
     vertices, faces, pixels, grad_pixels = (t.contiguous() for t in (vertices, faces, pixels, grad_pixels))
-    B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[1]
+    B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[-2]
+    if faces.dim() == 2:
+        flags |= _lib.FLAG_SHARED_FACES
     grad_background = torch.empty_like(pixels)
     debug = torch.empty((B, height, width, 3), dtype=torch.float32, device=dev) if want_debug else None
     with torch.cuda.device(dev):
@@ -189,14 +195,15 @@ def _op_visibility(vertices, faces, height, width):
     lib = _lib.load()
     dev = _require_gpu(vertices, faces)
     vertices, faces = vertices.contiguous(), faces.contiguous()
-    B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[1]
+    B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[-2]
+    flags = _lib.FLAG_SHARED_FACES if faces.dim() == 2 else 0
     face_id = torch.empty((B, height, width), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, 1)
         ws = _workspace(dev, nbytes)
         _lib.check(lib.dirt_rasterise_visibility(
             vertices.data_ptr(), faces.data_ptr(), face_id.data_ptr(), B, V, F, height, width,
-            ws.data_ptr(), ws.numel(), 0, torch.cuda.current_stream(dev).cuda_stream))
+            ws.data_ptr(), ws.numel(), flags, torch.cuda.current_stream(dev).cuda_stream))
     return face_id
 
 
@@ -247,7 +254,10 @@ def rasterise(background, vertices, vertex_colors, faces, height=None, width=Non
 
 def rasterise_batch(background, vertices, vertex_colors, faces, height=None, width=None, channels=None, name=None):
     """Rasterises a batch of meshes with the same numbers of vertices and faces
-    (dirt/rasterise_ops.py:51-108); every argument of `rasterise` gains a leading batch dimension."""
+    (dirt/rasterise_ops.py:51-108); every argument of `rasterise` gains a leading batch dimension.
+
+    Extension: `faces` may also be [face count, 3] -- one topology shared by the whole batch, which the reference
+    can only express by tiling it (the TODO at csrc/rasterise_egl.cpp:314, tests/rasterise_tests.py:89)."""
     like = _first_tensor(background, vertices, vertex_colors, faces)
     background = _as_tensor(background, torch.float32, like)
     vertices = _as_tensor(vertices, torch.float32, like)

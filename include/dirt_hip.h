@@ -62,6 +62,9 @@ extern "C" {
                                        frame size and the face density (32x32 raster / 32x16 gradient tiles) ... */
 #define DIRT_FLAG_TILES_SMALL 0x400u /* ... or 16x16 / 32x8 tiles.  Results do not depend on the shape (pixels and
                                        visibility bit for bit; gradients up to float-atomic order); for tests. */
+#define DIRT_FLAG_SHARED_FACES 0x800u /* `faces` is one [F,3] topology shared by all B scenes instead of [B,F,3] (the
+                                        TODO of csrc/rasterise_egl.cpp:314).  Same flag on the
+                                        forward, visibility and backward calls of one scene batch. */
 #define DIRT_FLAG_PROFILE 0x100u /* record a HIP-event pair around every kernel this call launches (on the
                                     call's stream); read the totals with dirt_profile_read.  Replaces the
                                     reference's compile-time TIME_SECTIONS wall-clock prints

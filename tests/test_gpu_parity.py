@@ -213,3 +213,33 @@ def test_thin_frames(gpu, oracle, H, W):
     assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
     _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
     _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
+
+
+def test_shared_topology(gpu, oracle):
+    """One [F,3] `faces` for the whole batch (DIRT_FLAG_SHARED_FACES; the reference tiles it,
+    tests/rasterise_tests.py:89) gives exactly what the tiled [B,F,3] tensor gives."""
+    B, H, W, C = 3, 60, 84, 3
+    base = scenes.rand_scene(300, H, W, C, 31, 0.03, 0.25, True)
+    rng = np.random.default_rng(7)
+    verts = np.stack([base['vertices'] * (1 + 0.05 * rng.standard_normal(base['vertices'].shape)).astype(np.float32) for _ in range(B)])
+    cols = rng.uniform(0, 1, (B,) + base['vertex_colors'].shape).astype(np.float32)
+    bg = rng.uniform(0, 1, (B, H, W, C)).astype(np.float32)
+    g = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    faces = base['faces']
+    tiled = np.ascontiguousarray(np.broadcast_to(faces, (B,) + faces.shape))
+
+    def run(f):
+        b_, v_, c_ = (_t(a, gpu).requires_grad_(True) for a in (bg, verts, cols))
+        px = ops.rasterise_batch(b_, v_, c_, _t(f, gpu))
+        px.backward(_t(g, gpu))
+        return px.detach().cpu().numpy(), b_.grad.cpu().numpy(), v_.grad.cpu().numpy(), c_.grad.cpu().numpy()
+
+    shared, ref = run(faces), run(tiled)
+    assert np.array_equal(shared[0], ref[0]) and np.array_equal(shared[1], ref[1])
+    want = oracle.forward(bg, verts, cols, tiled)
+    assert np.array_equal(shared[0].view(np.uint32), want.view(np.uint32))
+    ow = oracle.backward(verts, tiled, want, g)
+    _assert_grad_close(shared[2], ow['grad_vertices'], 'grad_vertices')
+    _assert_grad_close(shared[3], ow['grad_vertex_colors'], 'grad_vertex_colors')
+    vis = ops._op_visibility(_t(verts, gpu), _t(faces, gpu), H, W).cpu().numpy()
+    assert np.array_equal(vis, ops._op_visibility(_t(verts, gpu), _t(tiled, gpu), H, W).cpu().numpy())
