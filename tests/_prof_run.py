@@ -9,6 +9,7 @@ t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 H, W, C = s['height'], s['width'], s['channels']
 bg, v, vc, f, g = t(s['background'][None]), t(s['vertices'][None]), t(s['vertex_colors'][None]), t(s['faces'][None]), t(s['grad_pixels'][None])
 for it in range(n):
-    px = ops._op_rasterise(bg, v, vc, f, H, W, C)
-    out = ops._op_rasterise_grad(v, f, px, g, H, W, C)
+    # the step bench.py times: the forward leaves its state, the backward consumes it
+    px, state = ops._op_rasterise(bg, v, vc, f, H, W, C, keep_state=True)
+    out = ops._op_rasterise_grad(v, f, px, g, H, W, C, state=state)
 torch.cuda.synchronize()

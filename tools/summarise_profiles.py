@@ -19,8 +19,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import pmc_summary  # noqa: E402
 
-SLOT = {'grad_kernel': 'grad_kernel', 'raster_kernel<0>': 'raster_kernel<shade>', 'raster_kernel<1>': 'raster_kernel<visibility>',
-        'setup_kernel': 'setup_kernel', 'zero_kernel': 'zero_kernel'}
+def slot(kernel):
+    """rocprofv3 kernel name -> the library's profiling slot (dirt_profile_name), whatever the tile-shape template."""
+    if kernel.startswith('grad_kernel'):
+        return 'grad_kernel'
+    if kernel.startswith('raster_kernel<0'):
+        return 'raster_kernel<shade>'
+    if kernel.startswith('raster_kernel<1'):
+        return 'raster_kernel<visibility>'
+    return kernel
 
 
 def counter(path, name):
@@ -51,7 +58,7 @@ def main():
     traffic = {}
     for k in fetch:
         # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
-        traffic[SLOT.get(k, k)] = int(2 * fetch[k] * 1024 + write.get(k, 0) * 1024)
+        traffic[slot(k)] = int(2 * fetch[k] * 1024 + write.get(k, 0) * 1024)
     path = os.path.join(dst, 'pmc_traffic.json')
     allt = json.load(open(path)) if os.path.exists(path) else {}
     allt[config] = traffic
