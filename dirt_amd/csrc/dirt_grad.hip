@@ -108,16 +108,19 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
     return max(max(a, b), max(c, d));
 }
 
-// Open-addressing insert of `face` into the tile's slot table; returns the slot or -1 when full.
-__device__ inline int slot_insert(int32_t* keys, int nslots, int face)
+// Open-addressing insert of `face` into the tile's slot table; returns the slot or -1 when full.  `claimed` is
+// set for the one thread whose CAS created the slot.
+__device__ inline int slot_insert(int32_t* keys, int nslots, int face, bool& claimed)
 {
+    claimed = false;
     uint32_t h = ((uint32_t)face * 2654435761u) % (uint32_t)nslots;
     for (int probe = 0; probe < nslots; ++probe) {
         const int32_t cur = __hip_atomic_load(keys + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == face) return (int)h;
         if (cur == -1) {
             const int32_t prev = atomicCAS(&keys[h], -1, face);
-            if (prev == -1 || prev == face) return (int)h;
+            if (prev == -1) { claimed = true; return (int)h; }
+            if (prev == face) return (int)h;
         }
         h = (h + 1 == (uint32_t)nslots) ? 0u : h + 1;
     }
@@ -340,7 +343,8 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         }
     }
 
-    // ---- init ----
+    // ---- init: empty slot table, cleared accumulators (under the latency of the loads above) ----
+    for (int i = tid; i < MAX_SLOTS * NVAL * COPIES / 2; i += GTHREADS) reinterpret_cast<uint4*>(s_acc)[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < MAX_SLOTS; i += GTHREADS) s_key[i] = -1;
     if (tid < 3) s_bound[tid] = 0u;
     __syncthreads();
@@ -360,7 +364,12 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         int slot = -1;
         if (face >= 0) {
             w_min = fminf(w_min, fabsf(a_frag[j].w));
-            slot = slot_insert(s_key, MAX_SLOTS, face);
+            bool claimed;
+            slot = slot_insert(s_key, MAX_SLOTS, face, claimed);
+            if (claimed) {  // the thread that created the slot fetches the face's vertex indices for everybody
+                const FaceRec* __restrict__ rec = recs + face;
+                s_vid[slot][0] = rec->vid[0]; s_vid[slot][1] = rec->vid[1]; s_vid[slot][2] = rec->vid[2];
+            }
             if (slot < 0) slot = -2;
         }
         s_vis[vy][vx] = face;
@@ -421,26 +430,13 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         }
         __syncthreads();
         GMARK();  // 3 staged
-        if (c0 == 0) {
-            // the slot table is complete: fetch the vertex indices of the occupied slots, list them, and clear
-            // only their accumulators (typically ~20 of 64 slots are in use)
-            if (wave == 0) {
-                const int32_t face = s_key[lane];  // MAX_SLOTS == 64 == one wave
-                const bool used = face >= 0;
-                const unsigned long long um = __ballot(used);
-                if (used) {
-                    s_vid[lane][0] = recs[face].vid[0]; s_vid[lane][1] = recs[face].vid[1]; s_vid[lane][2] = recs[face].vid[2];
-                    s_used[__popcll(um & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-                }
-                if (lane == 0) s_nused = __popcll(um);
-            }
-            __syncthreads();
-            const int nused = s_nused;
-            for (int i = tid; i < nused * (NVAL * COPIES / 2); i += GTHREADS) {
-                const int u = i / (NVAL * COPIES / 2), j = i - u * (NVAL * COPIES / 2);
-                reinterpret_cast<uint4*>(s_acc)[(int)s_used[u] * (NVAL * COPIES / 2) + j] = make_uint4(0, 0, 0, 0);
-            }
-            __syncthreads();
+        if (c0 == 0 && wave == 0) {
+            // the slot table is complete: list the occupied slots for the flush (typically ~20 of 64); read after the
+            // barrier that separates accumulation from flush
+            const bool used = s_key[lane] >= 0;  // MAX_SLOTS == 64 == one wave
+            const unsigned long long um = __ballot(used);
+            if (used) s_used[__popcll(um & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+            if (lane == 0) s_nused = __popcll(um);
         }
         GMARK();  // 4 vids
 
