@@ -238,7 +238,7 @@ __device__ __forceinline__ float2 scharr_taps_wrapped(const float* __restrict__ 
     return make_float2(sx, sy);
 }
 
-template <int GH, int COPIES>
+template <int GH, int COPIES, int CSPEC>
 __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(GradParams p)
 {
     constexpr int GTHREADS = GW * GH;  // GH / 8 x 4 waves, one 8 x 8 block each
@@ -265,7 +265,10 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
     const int tile = xcd_tile(blockIdx.x, p.tiles_x * p.tiles_y);
     const int tx0 = (tile % p.tiles_x) * GW;
     const int tr0 = (tile / p.tiles_x) * GH;
-    const int H = p.H, W = p.W, C = p.C;
+    // CSPEC = 1, 3, 4: the channel count is that compile-time constant (4: with 16-byte aligned pixel tensors), which
+    // makes the pass / channel-group structure static; 0: any channel count
+    const int H = p.H, W = p.W, C = CSPEC ? CSPEC : p.C;
+    const bool aligned16 = CSPEC == 4 ? true : (p.pixels_aligned16 != 0);
     const size_t frame = (size_t)H * W;
     const size_t total_pix = (size_t)p.B * frame;
 
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
 
     // channels of a pass: whole channel groups (dirt/rasterise_ops.py:148-152) starting at c0 that fit in PC channels
     auto pass_channels = [&](int c0) {
+        if (CSPEC) return (int)CSPEC;  // 1, 3 or 4 channels are one pass
         int nch = 0;
         for (int c = c0; c < C && nch < PC;) {
             const int G = (c + 3 <= C) ? 3 : 1;
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
             const int yy = ii / PWU, xx = ii - yy * PWU;
             const int cy = min(max(tr0 + yy - 1, 0), H - 1), cx = min(max(tx0 + xx - 1, 0), W - 1);
             const float* src = pixels + ((size_t)cy * W + cx) * C + c0;
-            if (nch == 4 && (C & 3) == 0 && p.pixels_aligned16) {
+            if (nch == 4 && (C & 3) == 0 && aligned16) {
                 const float4 q = *reinterpret_cast<const float4*>(src);  // c0 is a multiple of 4 here
                 v[j][0] = q.x; v[j][1] = q.y; v[j][2] = q.z; v[j][3] = q.w;
             } else {
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         // ---- background gradient (:143-147) and colour gradients (:135-142) of the pass's channels ----
         if (inside) {
             float* gbk = p.grad_background + pix * C + c0;
-            if (nch == 4 && (C & 3) == 0 && p.pixels_aligned16) {
+            if (nch == 4 && (C & 3) == 0 && aligned16) {
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(gbk) = face_here >= 0 ? z : make_float4(gch[0], gch[1], gch[2], gch[3]);
             } else {
@@ -489,7 +493,10 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
 
         GMARK();  // colour done
         // ---- channel groups of the pass: Scharr, dilation, position gradients ----
-        for (int cg = 0; cg < nch;) {
+        int cg = 0;
+#pragma unroll
+        for (int gi = 0; gi < PC; ++gi) {  // at most PC groups in a pass
+            if (cg >= nch) break;
             const int c_begin = c0 + cg;
             const int G = (c_begin + 3 <= C) ? 3 : 1;
             const bool alias = (G == 1) && !q1_intended;  // quirk Q1: "channels" 1,2 of a 1-channel tensor
@@ -644,6 +651,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         }
         GMARK();  // 6 flushed
         c0 += nch;
+        if (CSPEC) break;  // a single pass, statically
         if (c0 < C) {
             __syncthreads();
             if (tid < 2) s_bound[tid] = 0u;  // |grad_pixels| and |pixels| bounds are per pass; 1/w is per tile
@@ -674,10 +682,19 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     p.nslots = MAX_SLOTS;
     p.pixels_aligned16 = ((reinterpret_cast<uintptr_t>(p.pixels) | reinterpret_cast<uintptr_t>(p.grad_background)) & 15u) == 0 ? 1 : 0;
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.B);
-    if (gh == 16)
-        hipLaunchKernelGGL((grad_kernel<16, 4>), grid, dim3(GW * 16), 0, stream, p);
-    else
-        hipLaunchKernelGGL((grad_kernel<8, 2>), grid, dim3(GW * 8), 0, stream, p);
+    // the common channel counts get kernels in which the pass / channel-group structure is static
+    const int cspec = (p.C == 4 && p.pixels_aligned16) ? 4 : (p.C == 3 ? 3 : (p.C == 1 ? 1 : 0));
+#define DIRT_LAUNCH_GRAD(GH_, CP_)                                                                          \
+    do {                                                                                                    \
+        const dim3 block(GW * GH_);                                                                         \
+        if (cspec == 4) hipLaunchKernelGGL((grad_kernel<GH_, CP_, 4>), grid, block, 0, stream, p);          \
+        else if (cspec == 3) hipLaunchKernelGGL((grad_kernel<GH_, CP_, 3>), grid, block, 0, stream, p);     \
+        else if (cspec == 1) hipLaunchKernelGGL((grad_kernel<GH_, CP_, 1>), grid, block, 0, stream, p);     \
+        else hipLaunchKernelGGL((grad_kernel<GH_, CP_, 0>), grid, block, 0, stream, p);                     \
+    } while (0)
+    if (gh == 16) DIRT_LAUNCH_GRAD(16, 4);
+    else DIRT_LAUNCH_GRAD(8, 2);
+#undef DIRT_LAUNCH_GRAD
     return hipGetLastError();
 }
 
