@@ -277,11 +277,12 @@ __device__ __forceinline__ void export_frag(const RasterParams& p, const FaceRec
 }
 
 // Shade one pixel: the winner's record is re-read, barycentrics and all C channels interpolated once.
+template <int CSPEC>
 __device__ __forceinline__ void shade_pixel(const RasterParams& p, const FaceRec* __restrict__ recs, int ib, int x, int r,
                                             double px, double py, int32_t f)
 {
     const size_t pix = ((size_t)ib * p.H + r) * p.W + x;
-    const int C = p.C;
+    const int C = CSPEC ? CSPEC : p.C;  // CSPEC = 1, 3, 4: compile-time channel count; 0: any
     float* __restrict__ out = p.pixels + pix * C;
     if (f < 0) {  // pixels start as the background: csrc/rasterise_egl.cpp:348-356
         if (p.frag) p.frag[pix] = make_float4(-1.f, -1.f, -1.f, INFINITY);  // clear values, csrc/rasterise_grad_egl.cpp:442-445
@@ -324,7 +325,7 @@ __device__ __forceinline__ void shade_pixel(const RasterParams& p, const FaceRec
     }
 }
 
-template <int MODE, int NB>
+template <int MODE, int NB, int CSPEC>
 __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
 {
     constexpr int TILE_W = 16 * NB, TILE_H = 16 * NB;  // pixels
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
         if (r >= p.H || x >= p.W) continue;
         const int32_t f = s_vis[i];
         if (MODE == 1 || p.vis) p.vis[((size_t)ib * p.H + r) * p.W + x] = f;
-        if (MODE == 0) shade_pixel(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
+        if (MODE == 0) shade_pixel<CSPEC>(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
         else if (p.frag) export_frag(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
     }
     TRACE_MARK();  // 7: stored
@@ -590,17 +591,18 @@ hipError_t launch_raster(const RasterParams& p_in, int B, bool visibility_only, 
     p.tiles_x = (p.W + tile - 1) / tile;
     p.tiles_y = (p.H + tile - 1) / tile;
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)B);
-    if (tile == 32) {
-        if (visibility_only)
-            hipLaunchKernelGGL((raster_kernel<1, 2>), grid, dim3(RTHREADS), 0, stream, p);
-        else
-            hipLaunchKernelGGL((raster_kernel<0, 2>), grid, dim3(RTHREADS), 0, stream, p);
-    } else {
-        if (visibility_only)
-            hipLaunchKernelGGL((raster_kernel<1, 1>), grid, dim3(RTHREADS), 0, stream, p);
-        else
-            hipLaunchKernelGGL((raster_kernel<0, 1>), grid, dim3(RTHREADS), 0, stream, p);
-    }
+    const int cspec = visibility_only ? 0 : (p.C == 4 ? 4 : (p.C == 3 ? 3 : (p.C == 1 ? 1 : 0)));
+#define DIRT_LAUNCH_RASTER(NB_)                                                                               \
+    do {                                                                                                      \
+        if (visibility_only) hipLaunchKernelGGL((raster_kernel<1, NB_, 0>), grid, dim3(RTHREADS), 0, stream, p);   \
+        else if (cspec == 4) hipLaunchKernelGGL((raster_kernel<0, NB_, 4>), grid, dim3(RTHREADS), 0, stream, p);   \
+        else if (cspec == 3) hipLaunchKernelGGL((raster_kernel<0, NB_, 3>), grid, dim3(RTHREADS), 0, stream, p);   \
+        else if (cspec == 1) hipLaunchKernelGGL((raster_kernel<0, NB_, 1>), grid, dim3(RTHREADS), 0, stream, p);   \
+        else hipLaunchKernelGGL((raster_kernel<0, NB_, 0>), grid, dim3(RTHREADS), 0, stream, p);                   \
+    } while (0)
+    if (tile == 32) DIRT_LAUNCH_RASTER(2);
+    else DIRT_LAUNCH_RASTER(1);
+#undef DIRT_LAUNCH_RASTER
     return hipGetLastError();
 }
 
