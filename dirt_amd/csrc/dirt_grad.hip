@@ -4,15 +4,14 @@
 // evaluating every channel group of dirt/rasterise_ops.py:145-165 inside one launch, the N
 // per-group RasteriseGrad ops (and N GL re-draws) the reference issues for C not in {1,3}.
 //
-// Inputs: the visibility buffer (front-most face per pixel, written by raster_kernel<1>) instead of
-// the reference's two RGBA32F surfaces; barycentrics and clip-w of a pixel are recomputed from the
-// face's set-up record exactly as the forward pass computes them.
+// Inputs: the visibility buffer (front-most face per pixel) and the fragment buffer ((b0,b1,b2,clip_w) per
+// pixel), both written by the raster kernel -- the counterpart of the reference's two RGBA32F surfaces
+// (csrc/rasterise_grad_egl.cpp:432-456), produced by the forward pass itself when it keeps its state.
 //
 // The reference issues up to 3C+9 global float atomics per covered pixel (:140,228-230) and reads
-// its 3x3 neighbourhood with 27 scalar loads.  Here one 512-thread workgroup owns a 32x16 tile (each
-// of its 8 waves one 8x8 block, one pixel per lane, as in raster_kernel); channel groups are
-// processed in turn, the group's channels of the `pixels` tile (+halo) staged in LDS, and per-face
-// partial sums are accumulated in LDS:
+// its 3x3 neighbourhood with 27 scalar loads.  Here one workgroup owns a 32 x GH tile (each wave one
+// 8x8 block, one pixel per lane); channel groups are processed in turn, the group's channels of the
+// `pixels` tile (+halo) staged in LDS, and per-face partial sums are accumulated in LDS:
 //   * the faces that receive gradient in the tile get a slot in a small LDS hash table (LDS CAS);
 //   * each value is first summed over the 4 lanes of a 4x1 pixel quad with two DPP quad_perm adds
 //     when the quad targets one face (the common case);
@@ -64,28 +63,6 @@ constexpr int NVAL = 9 + 3 * PC;       // 9 position values (3 vertices x {x,y,w
 #endif
 static_assert(MAX_SLOTS == 64, "the slot bookkeeping uses one wave for the table");
 constexpr int FIX_BITS = 29;           // fixed-point contributions: |q| < 2^FIX_BITS given the tile bound
-
-struct Frag {
-    float b[3];
-    float w;
-    int32_t vid[3];
-};
-
-// (barycentric, clip_w, indices) of face `f` at pixel (x, r): what the backward fragment shader
-// writes (csrc/shaders.cpp:64-77).
-__device__ inline Frag frag_eval(const FaceRec* __restrict__ recs, int f, int x, int r, int H)
-{
-    const FaceRec* __restrict__ rec = recs + f;
-    double cf[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) cf[k] = rec->coef[k];
-    double Fk[3];
-    edge_eval(cf, (double)x + 0.5, (double)(H - 1 - r) + 0.5, Fk);
-    Frag o;
-    bary_eval(Fk, rec->flags, rec->inv_det, o.b, o.w);
-    o.vid[0] = rec->vid[0]; o.vid[1] = rec->vid[1]; o.vid[2] = rec->vid[2];
-    return o;
-}
 
 __device__ __forceinline__ float quad_sum(float v)
 {
@@ -679,7 +656,6 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     if (p.flags & DIRT_FLAG_TILES_LARGE) gh = 16;
     if (p.flags & DIRT_FLAG_TILES_SMALL) gh = 8;
     p.tiles_y = (p.H + gh - 1) / gh;
-    p.nslots = MAX_SLOTS;
     p.pixels_aligned16 = ((reinterpret_cast<uintptr_t>(p.pixels) | reinterpret_cast<uintptr_t>(p.grad_background)) & 15u) == 0 ? 1 : 0;
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.B);
     // the common channel counts get kernels in which the pass / channel-group structure is static

@@ -75,7 +75,6 @@ struct GradParams {
     int B, V, F, H, W, C;
     unsigned flags;
     int tiles_x, tiles_y;      // filled by launch_grad
-    int nslots;                // LDS slot-table capacity, filled by launch_grad
     int pixels_aligned16;      // `pixels` may be read with 16-byte loads, filled by launch_grad
 };
 
