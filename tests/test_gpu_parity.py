@@ -243,3 +243,19 @@ def test_shared_topology(gpu, oracle):
     _assert_grad_close(shared[3], ow['grad_vertex_colors'], 'grad_vertex_colors')
     vis = ops._op_visibility(_t(verts, gpu), _t(faces, gpu), H, W).cpu().numpy()
     assert np.array_equal(vis, ops._op_visibility(_t(verts, gpu), _t(tiled, gpu), H, W).cpu().numpy())
+
+
+@pytest.mark.parametrize('H,W', [(48, 16384), (16384, 40)])
+def test_maximum_frame_dimension(gpu, oracle, H, W):
+    """A frame as wide / as tall as the library accepts (DIRT_MAX_DIM = 16384): bin grid, tile indexing and the
+    16-bit boxes at their limits; forward bit-exact, gradients within tolerance."""
+    s = _batched(scenes.rand_scene(500, H, W, 3, 51, 0.02, 0.6))
+    want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
+    got = _fwd_gpu(s, gpu)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'])
+    gb, gv, gvc, _ = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
+                                            _t(s['grad_pixels'], gpu), H, W, 3)
+    assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
+    _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
+    _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
