@@ -3,3 +3,4 @@
 from .rasterise_ops import rasterise, rasterise_batch, rasterise_deferred, rasterise_batch_deferred  # noqa: F401
 from . import rasterise_ops  # noqa: F401
 from . import matrices, lighting, projection  # noqa: F401  (dirt.matrices, dirt.lighting, dirt.projection)
+from . import texture  # noqa: F401  (the texture helpers of samples/textured.py)

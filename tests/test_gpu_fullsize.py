@@ -213,3 +213,25 @@ def test_simple_sample_end_to_end(gpu, oracle):
     ((px - target) ** 2).sum().backward()
     assert torch.isfinite(rotation.grad).all() and float(rotation.grad.abs().max()) > 0
     assert float(rotation.grad[1]) > 0  # turning back towards the target (smaller angle) lowers the loss
+
+
+def test_textured_sample_end_to_end(gpu):
+    """samples/textured.py on dirt_amd: deferred shading with a texture look-up; the loss reaches the texture,
+    the light direction and the vertices."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('example_textured', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'textured.py'))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    vertices, uvs, faces = (torch.from_numpy(a).to(gpu) for a in ex.build_cube())
+    texture = torch.from_numpy(ex.checker_texture()).to(gpu).requires_grad_(True)
+    light = torch.nn.functional.normalize(torch.tensor([1., -0.3, -0.5], device=gpu), dim=0).requires_grad_(True)
+    vertices.requires_grad_(True)
+    px = ex.render(vertices, uvs, faces, texture, light)
+    assert px.shape == (ex.frame_height, ex.frame_width, 3) and bool(torch.isfinite(px).all())
+    background = torch.tensor([0., 0., 0.3], device=gpu)
+    covered = (px - background).abs().sum(-1) > 1e-6
+    assert 0.1 < float(covered.float().mean()) < 0.7
+    (px ** 2).mean().backward()
+    for t in (texture, light, vertices):
+        assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0
