@@ -154,15 +154,18 @@ __device__ __forceinline__ FixScale fix_scale(float bound)
     return f;
 }
 
-// N fixed-point adds (values idx0 .. idx0+N-1 of the lane's slot) under one exec mask.
+// N fixed-point adds (values idx0 .. idx0+N-1 of the lane's slot) under one exec mask.  The values are already
+// scaled to the fixed-point unit (the scale is folded into the per-pixel factors they are products of); they are
+// rounded to the nearest integer with one v_cvt_rpi_i32_f32 (floor(x + 0.5)).
 template <int N, int COPIES>
-__device__ __forceinline__ void fix_add(unsigned long long* acc, const Target& t, int idx0, const float* v, float to_fix)
+__device__ __forceinline__ void fix_add(unsigned long long* acc, const Target& t, int idx0, const float* v)
 {
     if (t.active) {
         unsigned long long* a = &acc[(t.slot * NVAL + idx0) * COPIES + t.copy];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int q = (int)rintf(v[i] * to_fix);
+            int q;
+            asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(v[i]));
             atomicAdd(a + i * COPIES, (unsigned long long)(long long)q);
         }
     }
@@ -451,19 +454,23 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         {
             const bool col_lds = finite && slot_here != -2;
             const bool col_direct = !col_lds && face_here >= 0 && (t_here.active || slot_here == -2);
+            // g * b_k in fixed-point units: the scale is folded into g once (a power of two: exact)
+            float gs[PC];
+#pragma unroll
+            for (int c = 0; c < PC; ++c) gs[c] = (face_here >= 0 && c < nch) ? gch[c] * fc.to_fix : 0.f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float hbk = k == 0 ? fh4.x : (k == 1 ? fh4.y : fh4.z);
                 float cv[PC];
 #pragma unroll
-                for (int c = 0; c < PC; ++c) cv[c] = quad_reduce(t_here, (face_here >= 0 && c < nch) ? gch[c] * hbk : 0.f);
+                for (int c = 0; c < PC; ++c) cv[c] = quad_reduce(t_here, gs[c] * hbk);
                 if (col_lds) {
-                    fix_add<PC, COPIES>(s_acc, t_here, 9 + k * PC, cv, fc.to_fix);
+                    fix_add<PC, COPIES>(s_acc, t_here, 9 + k * PC, cv);
                 } else if (col_direct) {
                     // table full, or inf / NaN in the tile: the reference's direct float atomics
 #pragma unroll
                     for (int c = 0; c < PC; ++c)
-                        if (c < nch) atomicAdd(&grad_vertex_colors[(size_t)recs[face_here].vid[k] * C + c0 + c], cv[c]);
+                        if (c < nch) atomicAdd(&grad_vertex_colors[(size_t)recs[face_here].vid[k] * C + c0 + c], cv[c] * fc.from_fix);
                 }
             }
         }
@@ -580,23 +587,25 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
             const float d_yview_by_wclip = ((-.5f * height_f) * clip_y) * rcp_ww;
             const bool pos_lds = finite && slot_cur != -2;
             const bool pos_direct = !pos_lds && covered && (t_cur.active || slot_cur == -2);
+            // :224-230: the three components of vertex k are b_k times per-pixel factors; those carry the
+            // fixed-point scale (a power of two: exact) and are zero where nothing is covered
+            const float fx = covered ? (dL_dx * d_xview_by_xclip) * fp.to_fix : 0.f;
+            const float fy = covered ? (dL_dy * d_yview_by_yclip) * fp.to_fix : 0.f;
+            const float fw = covered ? (dL_dx * d_xview_by_wclip + dL_dy * d_yview_by_wclip) * fp.to_fix : 0.f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float cbk = k == 0 ? fc4.x : (k == 1 ? fc4.y : fc4.z);
-                const float dLx_b = dL_dx * cbk;
-                const float dLy_b = dL_dy * cbk;
-                const float gw1 = dLx_b * d_xview_by_wclip, gw2 = dLy_b * d_yview_by_wclip;
                 float pv[3];
-                pv[0] = quad_reduce(t_cur, covered ? dLx_b * d_xview_by_xclip : 0.f);
-                pv[1] = quad_reduce(t_cur, covered ? dLy_b * d_yview_by_yclip : 0.f);
-                pv[2] = quad_reduce(t_cur, covered ? gw1 + gw2 : 0.f);
+                pv[0] = quad_reduce(t_cur, fx * cbk);
+                pv[1] = quad_reduce(t_cur, fy * cbk);
+                pv[2] = quad_reduce(t_cur, fw * cbk);
                 if (pos_lds) {
-                    fix_add<3, COPIES>(s_acc, t_cur, 3 * k, pv, fp.to_fix);
+                    fix_add<3, COPIES>(s_acc, t_cur, 3 * k, pv);
                 } else if (pos_direct) {
                     float* gv = grad_vertices + (size_t)recs[face_cur].vid[k] * 4;
-                    atomicAdd(gv + 0, pv[0]);
-                    atomicAdd(gv + 1, pv[1]);
-                    atomicAdd(gv + 3, pv[2]);
+                    atomicAdd(gv + 0, pv[0] * fp.from_fix);
+                    atomicAdd(gv + 1, pv[1] * fp.from_fix);
+                    atomicAdd(gv + 3, pv[2] * fp.from_fix);
                 }
             }
             GMARK();  // fix_add
