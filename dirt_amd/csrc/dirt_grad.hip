@@ -31,6 +31,7 @@
 #include "dirt_device.h"
 #include "dirt_launch.h"
 #include "../../include/dirt_hip.h"
+#include <type_traits>
 
 namespace dirt {
 
@@ -367,8 +368,14 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
     }
     GMARK();  // 2 phase A body
 
-    for (int c0 = 0; c0 < C;) {
-        const int nch = pass_channels(c0);
+    // One pass = the channel groups that fit in PC channels, starting at channel c0.  A pass has one of four
+    // shapes -- {3}, {3,1}, {1}, {1,1} (dirt/rasterise_ops.py:148-152 packs groups of 3 while >= 3 channels remain,
+    // then singles) -- and the body is instantiated for each, so that its loops and branches over channels and
+    // groups are static: NCH channels, the first group of size G0, every further group a single channel.
+    auto run_pass = [&](auto nch_tag, auto g0_tag, const int c0) {
+        constexpr int NCH = decltype(nch_tag)::value;
+        constexpr int G0 = decltype(g0_tag)::value;
+        constexpr int nch = NCH;
         // ---- stage the pass's channels of the pixels tile (+halo), edge clamped: at(), :113-124 ----
         float pmax = 0.f, gmax = 0.f;
         float stage_v[2][PC];
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         for (int gi = 0; gi < PC; ++gi) {  // at most PC groups in a pass
             if (cg >= nch) break;
             const int c_begin = c0 + cg;
-            const int G = (c_begin + 3 <= C) ? 3 : 1;
+            const int G = (gi == 0) ? G0 : 1;
             const bool alias = (G == 1) && !q1_intended;  // quirk Q1: "channels" 1,2 of a 1-channel tensor
 
             // Scharr (:126-127), streamed per channel into what is needed of it: the L1 norms of :185 (all three
@@ -636,6 +643,19 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
             }
         }
         GMARK();  // 6 flushed
+    };
+    using std::integral_constant;
+    for (int c0 = 0; c0 < C;) {
+        const int nch = pass_channels(c0);
+        if (CSPEC) {
+            run_pass(integral_constant<int, CSPEC ? CSPEC : 1>{}, integral_constant<int, CSPEC == 1 ? 1 : 3>{}, 0);
+        } else if (c0 + 3 <= C) {
+            if (nch == 4) run_pass(integral_constant<int, 4>{}, integral_constant<int, 3>{}, c0);
+            else run_pass(integral_constant<int, 3>{}, integral_constant<int, 3>{}, c0);
+        } else {
+            if (nch == 2) run_pass(integral_constant<int, 2>{}, integral_constant<int, 1>{}, c0);
+            else run_pass(integral_constant<int, 1>{}, integral_constant<int, 1>{}, c0);
+        }
         c0 += nch;
         if (CSPEC) break;  // a single pass, statically
         if (c0 < C) {
