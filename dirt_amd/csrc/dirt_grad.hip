@@ -120,7 +120,7 @@ __device__ __forceinline__ Target make_target(int slot, int lane)
     Target t;
     t.slot = slot;
     const int s0 = __builtin_amdgcn_mov_dpp(slot, 0x00, 0xF, 0xF, true);  // quad_perm [0,0,0,0]
-    const unsigned long long m = __ballot(slot == s0);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(slot == s0);
     t.uniform = ((m >> (lane & ~3)) & 0xFull) == 0xFull && slot != -2;  // -2 lanes may belong to different faces
     t.active = slot >= 0 && (t.uniform ? (lane & 3) == 0 : true);
     t.copy = (lane >> 2) & (COPIES - 1);
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
             // the slot table is complete: list the occupied slots for the flush (typically ~20 of 64); read after the
             // barrier that separates accumulation from flush
             const bool used = s_key[lane] >= 0;  // MAX_SLOTS == 64 == one wave
-            const unsigned long long um = __ballot(used);
+            const unsigned long long um = __builtin_amdgcn_ballot_w64(used);
             if (used) s_used[__popcll(um & ((1ull << lane) - 1ull))] = (uint8_t)lane;
             if (lane == 0) s_nused = __popcll(um);
         }
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
                     // image row (then it wraps to the next row: read from global memory).
                     scharr_taps(&s_pix[cg][py_l][min(px_l + ch, PW - 2)], sxc, syc);
                     const bool wraps = interior && x_in_frame + 1 + ch > W - 1;
-                    if (__ballot(wraps) != 0ull) {  // only tiles on the right image border
+                    if (__builtin_amdgcn_ballot_w64(wraps) != 0ull) {  // only tiles on the right image border
                         if (wraps) {
                             const float2 w2 = scharr_taps_wrapped(p.pixels, total_pix,
                                                                   (size_t)iib * frame + (size_t)y_in_frame * W + x_in_frame + ch, W, C, c_begin);
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
                     const bool t2 = s_vid[c2][0] != hv0 || s_vid[c2][1] != hv1 || s_vid[c2][2] != hv2;
                     const bool g1 = d1 && (slot_here < 0 || s1 < 0), g2 = d2 && (slot_here < 0 || s2 < 0);
                     d1 = d1 && t1; d2 = d2 && t2;
-                    if (__ballot(g1 || g2) != 0ull) {  // some face has no slot (table full): compare through the records
+                    if (__builtin_amdgcn_ballot_w64(g1 || g2) != 0ull) {  // some face has no slot (table full): compare through the records
                         if (g1) d1 = triple_differs_global(recs, face_here, f1);
                         if (g2) d2 = triple_differs_global(recs, face_here, f2);
                     }

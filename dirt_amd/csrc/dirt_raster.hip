@@ -222,15 +222,16 @@ __device__ __forceinline__ void raster_block(const TileRec& t, const FaceRec* __
     const float hi = fminf(fminf(E0 + t.bnd[0], E1 + t.bnd[1]), E2 + t.bnd[2]);
     bool cov = lo > 0.f;                             // certainly inside
     const bool unsure = !(lo > 0.f) && !(hi < 0.f);  // neither certainly inside nor outside (NaN lands here)
-    if (__builtin_expect(__ballot(unsure) != 0ull, 0)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(unsure) != 0ull, 0)) {
         if (unsure) cov = covered_exact(recs + t.face, px, py);
     }
-    if (__ballot(cov) == 0ull) return;
+    if (__builtin_amdgcn_ballot_w64(cov) == 0ull) return;
     const double q = fma(t.zp[0], px, qrow);  // depth scaled to [0, 2^24-1]; kept iff inside (the depth clip)
     const uint32_t z24 = (uint32_t)rint(q);
     // GL_LESS against the stored depth; equal depth keeps the lower face index, which is what drawing the
     // faces in index order does (csrc/rasterise_egl.cpp:373-379)
-    const bool wins = cov && q >= 0.0 && q <= 16777215.0 && (z24 < zbest || (z24 == zbest && t.face < fbest));
+    // (bitwise, not short-circuit, operators: one predicated update instead of nested divergent branches)
+    const bool wins = cov & (q >= 0.0) & (q <= 16777215.0) & ((z24 < zbest) | ((z24 == zbest) & (t.face < fbest)));
     zbest = wins ? z24 : zbest;
     fbest = wins ? t.face : fbest;
 }
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
                 en = scene_entries[s_run_base[lo] + ((uint32_t)e - s_pre[lo])];
                 hit = en.box.i_min <= tx1 && en.box.i_max >= tx0 && en.box.r_min <= tr1 && en.box.r_max >= tr0;
             }
-            const unsigned long long m = __ballot(hit);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
             TRACE_MARK();  // 3: entries loaded
             if (m) {
                 uint32_t off = 0;
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
                 for (int by = 0; by < NB; ++by)
                     mym4 |= ((mk >> ((NB * wy + by) * BT + NB * wx)) & ((1u << NB) - 1u)) << (NB * by);
             }
-            unsigned long long m = __ballot(mym4 != 0);
+            unsigned long long m = __builtin_amdgcn_ballot_w64(mym4 != 0);
             while (m) {
                 const int k = __ffsll((long long)m) - 1;
                 m &= m - 1;
