@@ -121,8 +121,8 @@ __device__ __forceinline__ Target make_target(int slot, int lane)
     t.slot = slot;
     const int s0 = __builtin_amdgcn_mov_dpp(slot, 0x00, 0xF, 0xF, true);  // quad_perm [0,0,0,0]
     const unsigned long long m = __builtin_amdgcn_ballot_w64(slot == s0);
-    t.uniform = ((m >> (lane & ~3)) & 0xFull) == 0xFull && slot != -2;  // -2 lanes may belong to different faces
-    t.active = slot >= 0 && (t.uniform ? (lane & 3) == 0 : true);
+    t.uniform = (((m >> (lane & ~3)) & 0xFull) == 0xFull) & (slot != -2);  // -2 lanes may belong to different faces
+    t.active = (slot >= 0) & (!t.uniform | ((lane & 3) == 0));
     t.copy = (lane >> 2) & (COPIES - 1);
     return t;
 }
@@ -539,22 +539,24 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
                 const float w_here = fh4.w;
                 // index triples differ (:86-89): an uncovered pixel (-1,-1,-1) differs from any face; two faces
                 // with slots compare by canonical slot; a face without a slot (table full) through its record
-                bool d1 = f1 >= 0 && f1 != face_here, d2 = f2 >= 0 && f2 != face_here;
-                if (face_here >= 0) {
+                // (bitwise operators throughout: straight-line predicated code, no divergent branches around the LDS reads)
+                bool d1 = (f1 >= 0) & (f1 != face_here), d2 = (f2 >= 0) & (f2 != face_here);
+                {
                     // distinct faces over the same three vertices count as equal (:86-89): compare the triples
+                    const bool here = face_here >= 0;
                     const int c1 = max(s1, 0), c2 = max(s2, 0);
-                    const bool t1 = s_vid[c1][0] != hv0 || s_vid[c1][1] != hv1 || s_vid[c1][2] != hv2;
-                    const bool t2 = s_vid[c2][0] != hv0 || s_vid[c2][1] != hv1 || s_vid[c2][2] != hv2;
-                    const bool g1 = d1 && (slot_here < 0 || s1 < 0), g2 = d2 && (slot_here < 0 || s2 < 0);
-                    d1 = d1 && t1; d2 = d2 && t2;
-                    if (__builtin_amdgcn_ballot_w64(g1 || g2) != 0ull) {  // some face has no slot (table full): compare through the records
+                    const bool t1 = (s_vid[c1][0] != hv0) | (s_vid[c1][1] != hv1) | (s_vid[c1][2] != hv2);
+                    const bool t2 = (s_vid[c2][0] != hv0) | (s_vid[c2][1] != hv1) | (s_vid[c2][2] != hv2);
+                    const bool g1 = here & d1 & ((slot_here < 0) | (s1 < 0)), g2 = here & d2 & ((slot_here < 0) | (s2 < 0));
+                    d1 = d1 & (t1 | !here); d2 = d2 & (t2 | !here);
+                    if (__builtin_amdgcn_ballot_w64(g1 | g2) != 0ull) {  // some face has no slot (table full): compare through the records
                         if (g1) d1 = triple_differs_global(recs, face_here, f1);
                         if (g2) d2 = triple_differs_global(recs, face_here, f2);
                     }
                 }
-                const bool ok1 = interior && d1 && w_here > w1;          // :165, first attempt (:191)
-                const bool ok2 = interior && !ok1 && d2 && w_here > w2;  // opposite direction if the first failed (:192-193)
-                dilated = ok1 || ok2;
+                const bool ok1 = interior & d1 & (w_here > w1);          // :165, first attempt (:191)
+                const bool ok2 = interior & !ok1 & d2 & (w_here > w2);   // opposite direction if the first failed (:192-193)
+                dilated = ok1 | ok2;
                 cy_l = ok1 ? y1 : (ok2 ? y2 : py_l);
                 cx_l = ok1 ? x1 : (ok2 ? x2 : px_l);
             }
