@@ -529,13 +529,16 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
             int cy_l = py_l, cx_l = px_l;  // position (in the halo'd tile) of the fragment used
             bool dilated = false;
             {
-                int off_x = l1x > l1y ? 1 : 0, off_y = l1x > l1y ? 0 : 1;                    // :185
-                if (((x_in_frame + y_in_frame) & 1) == 1) { off_x = -off_x; off_y = -off_y; }  // :186-190
-                // the reference offsets in GL buffer orientation (y up): tensor row = y - offset_y
-                const int y1 = py_l - off_y, x1 = px_l + off_x, y2 = py_l + off_y, x2 = px_l - off_x;
-                const int32_t f1 = s_vis[y1][x1], f2 = s_vis[y2][x2];
-                const int s1 = s_slot[y1][x1], s2 = s_slot[y2][x2];
-                const float w1 = s_frag[y1][x1].w, w2 = s_frag[y2][x2].w;
+                // direction: x if L1(Sx) > L1(Sy) else y (:185), negated on odd (x + y) (:186-190).  The reference's
+                // offsets are in GL buffer orientation (y up): tensor row = y - offset_y.  The three LDS tiles share
+                // the row stride VW, so a neighbour is one signed element offset `d` away in each of them.
+                const bool horiz = l1x > l1y;
+                const int sgn = ((x_in_frame + y_in_frame) & 1) ? -1 : 1;
+                const int d = horiz ? sgn : -sgn * VW;
+                const int e0 = py_l * VW + px_l, e1 = e0 + d, e2 = e0 - d;
+                const int32_t f1 = (&s_vis[0][0])[e1], f2 = (&s_vis[0][0])[e2];
+                const int s1 = (&s_slot[0][0])[e1], s2 = (&s_slot[0][0])[e2];
+                const float w1 = (&s_frag[0][0])[e1].w, w2 = (&s_frag[0][0])[e2].w;
                 const float w_here = fh4.w;
                 // index triples differ (:86-89): an uncovered pixel (-1,-1,-1) differs from any face; two faces
                 // with slots compare by canonical slot; a face without a slot (table full) through its record
@@ -557,8 +560,9 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
                 const bool ok1 = interior & d1 & (w_here > w1);          // :165, first attempt (:191)
                 const bool ok2 = interior & !ok1 & d2 & (w_here > w2);   // opposite direction if the first failed (:192-193)
                 dilated = ok1 | ok2;
-                cy_l = ok1 ? y1 : (ok2 ? y2 : py_l);
-                cx_l = ok1 ? x1 : (ok2 ? x2 : px_l);
+                const int dsel = ok1 ? d : (ok2 ? -d : 0);
+                cy_l = py_l + (horiz ? 0 : (dsel > 0 ? 1 : (dsel < 0 ? -1 : 0)));
+                cx_l = px_l + (horiz ? dsel : 0);
             }
 
             if (p.debug_thingy && c_begin == 0 && inside) {  // :150-151,172
