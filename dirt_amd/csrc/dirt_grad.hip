@@ -32,6 +32,7 @@
 #include "dirt_launch.h"
 #include "../../include/dirt_hip.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace dirt {
 
@@ -243,9 +244,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int iib = blockIdx.y;
-    const int tile = xcd_tile(blockIdx.x, p.tiles_x * p.tiles_y);
-    const int tx0 = (tile % p.tiles_x) * GW;
-    const int tr0 = (tile / p.tiles_x) * GH;
+    const int ntiles = p.tiles_x * p.tiles_y;
     // CSPEC = 1, 3, 4: the channel count is that compile-time constant (4: with 16-byte aligned pixel tensors), which
     // makes the pass / channel-group structure static; 0: any channel count
     const int H = p.H, W = p.W, C = CSPEC ? CSPEC : p.C;
@@ -260,15 +259,8 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
     float* __restrict__ grad_vertices = p.grad_vertices + (size_t)iib * p.V * 4;
     float* __restrict__ grad_vertex_colors = p.grad_vertex_colors + (size_t)iib * p.V * C;
 
-    // ---- this lane's pixel ----
-    const int px_l = (wave & 3) * 8 + (lane & 7) + 1, py_l = (wave >> 2) * 8 + (lane >> 3) + 1;  // in the halo'd tile
-    const int x_in_frame = tx0 + px_l - 1;
-    const int y_in_frame = tr0 + py_l - 1;  // tensor row (top row first)
-    const bool inside = x_in_frame < W && y_in_frame < H;
-    const int xs = min(x_in_frame, W - 1), ys = min(y_in_frame, H - 1);  // safe addresses for idle lanes
-    const size_t pix = (size_t)iib * frame + (size_t)ys * W + xs;
-    const float* __restrict__ g_here = p.grad_pixels + pix * C;
-    const bool interior = inside && x_in_frame > 0 && y_in_frame > 0 && x_in_frame < W - 1 && y_in_frame < H - 1;
+    // ---- this lane's pixel inside the halo'd tile ----
+    const int px_l = (wave & 3) * 8 + (lane & 7) + 1, py_l = (wave >> 2) * 8 + (lane >> 3) + 1;
     const bool q1_intended = (p.flags & DIRT_FLAG_Q1_INTENDED) != 0;
     const float width_f = (float)W, height_f = (float)H;
 
@@ -285,7 +277,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
     };
     // loads of the pass's channels of the pixels tile (+halo), edge clamped (at(), :113-124): two positions per
     // thread (PH * PWU <= 2 * GTHREADS), every load issued before any use so the tile costs one memory latency
-    auto stage_load = [&](int c0, int nch, float (&v)[2][PC]) {
+    auto stage_load = [&](int tx0, int tr0, int c0, int nch, float (&v)[2][PC]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int ii = min(tid + j * GTHREADS, PH * PWU - 1);
@@ -301,39 +293,56 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
             }
         }
     };
-    // the first pass's tile and this pixel's grad_pixels are requested now: their latency overlaps phase A
-    float stage0_v[2][PC];
-    stage_load(0, pass_channels(0), stage0_v);
-    float g0v[PC];
-    {
-        const int nch0 = pass_channels(0);
-#pragma unroll
-        for (int c = 0; c < PC; ++c) g0v[c] = c < nch0 ? g_here[c] : 0.f;
-    }
-
-    // so is the visibility of the halo'd tile: PH * VWU positions, APOS per thread
+    // What a tile needs from global memory before anything can happen: the visibility and fragments of the halo'd
+    // tile (PH * VWU positions, APOS per thread), the first pass's channels of the `pixels` tile and this pixel's
+    // grad_pixels.  All loads are issued back to back; a workgroup that processes several tiles requests the next
+    // tile's while it computes on the current one.
     constexpr int APOS = (PH * VWU + GTHREADS - 1) / GTHREADS;
-    int32_t a_face[APOS];
-    float4 a_frag[APOS];
+    struct TileIn {
+        int32_t a_face[APOS];
+        float4 a_frag[APOS];
+        float stage0_v[2][PC];
+        float g0v[PC];
+    };
+    auto load_inputs = [&](int tile_linear, TileIn& in) {
+        const int tile = xcd_tile(tile_linear, ntiles);
+        const int tx0 = (tile % p.tiles_x) * GW, tr0 = (tile / p.tiles_x) * GH;
+        stage_load(tx0, tr0, 0, pass_channels(0), in.stage0_v);
+        {
+            const int xs = min(tx0 + px_l - 1, W - 1), ys = min(tr0 + py_l - 1, H - 1);  // safe addresses for idle lanes
+            const float* __restrict__ g = p.grad_pixels + ((size_t)iib * frame + (size_t)ys * W + xs) * C;
+            const int nch0 = pass_channels(0);
 #pragma unroll
-    for (int j = 0; j < APOS; ++j) {
-        const int i = tid + j * GTHREADS;
-        a_face[j] = -1;
-        a_frag[j] = make_float4(-1.f, -1.f, -1.f, INFINITY);
-        if (i < PH * VWU) {
-            const int vy = i / VWU, vx = i - vy * VWU;
-            const int rr = min(max(tr0 + vy - 1, 0), H - 1), xx = min(max(tx0 + vx - 1, 0), W - 1);
-            a_face[j] = vis[(size_t)rr * W + xx];
-            a_frag[j] = frag[(size_t)rr * W + xx];
+            for (int c = 0; c < PC; ++c) in.g0v[c] = c < nch0 ? g[c] : 0.f;
         }
-    }
+#pragma unroll
+        for (int j = 0; j < APOS; ++j) {
+            const int i = tid + j * GTHREADS;
+            in.a_face[j] = -1;
+            in.a_frag[j] = make_float4(-1.f, -1.f, -1.f, INFINITY);
+            if (i < PH * VWU) {
+                const int vy = i / VWU, vx = i - vy * VWU;
+                const int rr = min(max(tr0 + vy - 1, 0), H - 1), xx = min(max(tx0 + vx - 1, 0), W - 1);
+                in.a_face[j] = vis[(size_t)rr * W + xx];
+                in.a_frag[j] = frag[(size_t)rr * W + xx];
+            }
+        }
+    };
 
-    // ---- init: empty slot table, cleared accumulators (under the latency of the loads above) ----
-    for (int i = tid; i < MAX_SLOTS * NVAL * COPIES / 2; i += GTHREADS) reinterpret_cast<uint4*>(s_acc)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < MAX_SLOTS; i += GTHREADS) s_key[i] = -1;
-    if (tid < 3) s_bound[tid] = 0u;
-    __syncthreads();
-    GMARK();  // 1 init
+    // One tile.  `in`: its inputs (already requested); next_linear >= 0: the tile this workgroup processes next, whose
+    // inputs are requested into `nxt` as soon as this tile's are consumed.  Entered with an empty slot table, zero
+    // bounds and zero accumulators.
+    auto process_tile = [&](const int tile_linear, const TileIn& in, const int next_linear, TileIn& nxt) {
+    const int tile = xcd_tile(tile_linear, ntiles);
+    const int tx0 = (tile % p.tiles_x) * GW;
+    const int tr0 = (tile / p.tiles_x) * GH;
+    const int x_in_frame = tx0 + px_l - 1;
+    const int y_in_frame = tr0 + py_l - 1;  // tensor row (top row first)
+    const bool inside = x_in_frame < W && y_in_frame < H;
+    const int xs = min(x_in_frame, W - 1), ys = min(y_in_frame, H - 1);  // safe addresses for idle lanes
+    const size_t pix = (size_t)iib * frame + (size_t)ys * W + xs;
+    const float* __restrict__ g_here = p.grad_pixels + pix * C;
+    const bool interior = inside && x_in_frame > 0 && y_in_frame > 0 && x_in_frame < W - 1 && y_in_frame < H - 1;
 
     // ---- phase A: the visibility "surfaces" of the tile + 1-pixel halo, what the backward fragment
     //      shader writes (csrc/shaders.cpp:64-77) over the clear values of
@@ -345,10 +354,10 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         const int i = tid + j * GTHREADS;
         if (i >= PH * VWU) continue;
         const int vy = i / VWU, vx = i - vy * VWU;
-        const int32_t face = a_face[j];
+        const int32_t face = in.a_face[j];
         int slot = -1;
         if (face >= 0) {
-            w_min = fminf(w_min, fabsf(a_frag[j].w));
+            w_min = fminf(w_min, fabsf(in.a_frag[j].w));
             bool claimed;
             slot = slot_insert(s_key, MAX_SLOTS, face, claimed);
             if (claimed) {  // the thread that created the slot fetches the face's vertex indices for everybody
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
             if (slot < 0) slot = -2;
         }
         s_vis[vy][vx] = face;
-        s_frag[vy][vx] = a_frag[j];
+        s_frag[vy][vx] = in.a_frag[j];
         s_slot[vy][vx] = (int16_t)slot;
     }
     {
@@ -383,9 +392,9 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int ch = 0; ch < PC; ++ch) stage_v[j][ch] = stage0_v[j][ch];  // loaded before phase A
+                for (int ch = 0; ch < PC; ++ch) stage_v[j][ch] = in.stage0_v[j][ch];  // requested before phase A
         } else {
-            stage_load(c0, nch, stage_v);
+            stage_load(tx0, tr0, c0, nch, stage_v);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         float gch[PC];
 #pragma unroll
         for (int c = 0; c < PC; ++c) {
-            gch[c] = c0 == 0 ? g0v[c] : ((c < nch) ? g_here[c0 + c] : 0.f);
+            gch[c] = c0 == 0 ? in.g0v[c] : ((c < nch) ? g_here[c0 + c] : 0.f);
             gmax = fmaxf(gmax, fabsf(gch[c]));
         }
         // (NaNs do not survive fmaxf: they are folded in explicitly so the inf/NaN fallback sees them)
@@ -421,6 +430,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         }
         __syncthreads();
         GMARK();  // 3 staged
+        if (CSPEC && next_linear >= 0) load_inputs(next_linear, nxt);  // in flight while this tile is computed
         if (c0 == 0 && wave == 0) {
             // the slot table is complete: list the occupied slots for the flush (typically ~20 of 64); read after the
             // barrier that separates accumulation from flush
@@ -626,6 +636,10 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         }
         GMARK();  // 5 accumulated
         __syncthreads();
+        if (CSPEC && next_linear >= 0) {  // the next tile's empty slot table and bounds (nothing reads them any more)
+            for (int i = tid; i < MAX_SLOTS; i += GTHREADS) s_key[i] = -1;
+            if (tid < 3) s_bound[tid] = 0u;
+        }
 
         // ---- flush: one global atomic per (face, vertex, component) for the whole tile and pass ----
         const int nused_f = s_nused;
@@ -649,6 +663,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
             }
         }
         GMARK();  // 6 flushed
+        if (CSPEC && next_linear >= 0) __syncthreads();  // the flush has read s_vid / s_used; the next tile may claim slots
     };
     using std::integral_constant;
     for (int c0 = 0; c0 < C;) {
@@ -669,6 +684,24 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
             if (tid < 2) s_bound[tid] = 0u;  // |grad_pixels| and |pixels| bounds are per pass; 1/w is per tile
             __syncthreads();
         }
+    }
+    };  // process_tile
+
+    // ---- the workgroup's tiles: blockIdx.x, blockIdx.x + gridDim.x, ...  (one tile when the grid covers them all) ----
+    TileIn cur, nxt;
+    load_inputs((int)blockIdx.x, cur);
+    // empty slot table, cleared accumulators (under the latency of the loads above); a flush leaves them cleared
+    for (int i = tid; i < MAX_SLOTS * NVAL * COPIES / 2; i += GTHREADS) reinterpret_cast<uint4*>(s_acc)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < MAX_SLOTS; i += GTHREADS) s_key[i] = -1;
+    if (tid < 3) s_bound[tid] = 0u;
+    __syncthreads();
+    GMARK();  // 1 init
+    for (int t = (int)blockIdx.x;;) {
+        const int tn = (CSPEC && t + (int)gridDim.x < ntiles) ? t + (int)gridDim.x : -1;
+        process_tile(t, cur, tn, nxt);
+        if (tn < 0) break;
+        cur = nxt;
+        t = tn;
     }
 #ifdef DIRT_TRACE
     if (lane == 0 && g_trace_grad) {
@@ -692,9 +725,20 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     if (p.flags & DIRT_FLAG_TILES_SMALL) gh = 8;
     p.tiles_y = (p.H + gh - 1) / gh;
     p.pixels_aligned16 = ((reinterpret_cast<uintptr_t>(p.pixels) | reinterpret_cast<uintptr_t>(p.grad_background)) & 15u) == 0 ? 1 : 0;
-    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.B);
     // the common channel counts get kernels in which the pass / channel-group structure is static
     const int cspec = (p.C == 4 && p.pixels_aligned16) ? 4 : (p.C == 3 ? 3 : (p.C == 1 ? 1 : 0));
+    // The channel-specialised kernels process several tiles per workgroup (the next tile's inputs are requested while
+    // the current one is computed) when there are enough tiles to keep every CU busy regardless.
+    const long long ntiles = (long long)p.tiles_x * p.tiles_y;
+    int tiles_per_wg = 1;
+    if (cspec) {
+        for (tiles_per_wg = 4; tiles_per_wg > 1 && ntiles * p.B / tiles_per_wg < 512; tiles_per_wg >>= 1) {}
+        if (const char* env = getenv("DIRT_GRAD_TILES_PER_WG")) {  // tests pin it (any value >= 1)
+            const int v = atoi(env);
+            if (v >= 1) tiles_per_wg = v;
+        }
+    }
+    const dim3 grid((unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg), (unsigned)p.B);
 #define DIRT_LAUNCH_GRAD(GH_, CP_)                                                                          \
     do {                                                                                                    \
         const dim3 block(GW * GH_);                                                                         \

@@ -259,3 +259,22 @@ def test_maximum_frame_dimension(gpu, oracle, H, W):
     assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
     _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
     _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
+
+
+@pytest.mark.parametrize('tiles_per_wg', ['1', '2', '3', '7'])
+@pytest.mark.parametrize('C', [1, 3, 4])
+def test_several_gradient_tiles_per_workgroup(gpu, oracle, monkeypatch, tiles_per_wg, C):
+    """The channel-specialised gradient kernels walk several tiles per workgroup on large frames (the next tile's
+    inputs are requested while the current one is computed); pinned here on a small frame, including a count that
+    does not divide the number of tiles."""
+    monkeypatch.setenv('DIRT_GRAD_TILES_PER_WG', tiles_per_wg)
+    H, W = 100, 150
+    s = _batched(scenes.rand_scene(700, H, W, C, 61, 0.02, 0.2))
+    want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
+    for tiles in (0x200, 0x400):
+        ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'])
+        gb, gv, gvc, _ = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
+                                                _t(s['grad_pixels'], gpu), H, W, C, flags=tiles)
+        assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
+        _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
+        _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
