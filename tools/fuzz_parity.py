@@ -1,0 +1,55 @@
+"""Randomised parity sweep on an MI355X box: random frame sizes, channel counts, meshes (split / shared / hostile),
+kernel tile shapes, tiles per workgroup and flags; every case compares the HIP path with the CPU oracle (forward
+and visibility bit for bit, gradients within 1e-4 of the tensor scale).  Not part of the test suite (open-ended);
+usage: python tools/fuzz_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import oracle  # noqa: E402
+from dirt_amd import scenes, rasterise_ops as ops  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    dev = torch.device('cuda', 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    t0, n = time.time(), 0
+    while time.time() - t0 < budget:
+        H, W = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        C = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 10]))
+        kind = rng.choice(['split', 'shared', 'hostile', 'tiny'])
+        seed = int(rng.integers(0, 1 << 30))
+        if kind == 'hostile':
+            s = scenes.hostile_scene(H, W, C, seed, int(rng.integers(10, 1500)))
+        elif kind == 'tiny':
+            s = scenes.rand_scene(int(rng.integers(1, 4000)), H, W, C, seed, 0.001, 0.02)
+        else:
+            s = scenes.rand_scene(int(rng.integers(1, 3000)), H, W, C, seed, float(rng.uniform(0.005, 0.1)), float(rng.uniform(0.1, 0.8)), kind == 'shared')
+        flags = int(rng.choice([0, 0x200, 0x400])) | int(rng.choice([0, 1]))
+        os.environ['DIRT_GRAD_TILES_PER_WG'] = str(int(rng.choice([1, 2, 3, 4, 5])))
+        b = {k: v[None] for k, v in s.items() if isinstance(v, np.ndarray)}
+        want = oracle.forward(b['background'], b['vertices'], b['vertex_colors'], b['faces'])
+        got = ops._op_rasterise(t(b['background']), t(b['vertices']), t(b['vertex_colors']), t(b['faces']), H, W, C, flags=flags & ~1)
+        tag = (kind, H, W, C, seed, hex(flags), os.environ['DIRT_GRAD_TILES_PER_WG'])
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), ('forward', tag)
+        ow = oracle.backward(b['vertices'], b['faces'], want, b['grad_pixels'], flags=flags & 1)
+        gb, gv, gvc, _ = ops._op_rasterise_grad(t(b['vertices']), t(b['faces']), t(want), t(b['grad_pixels']), H, W, C, flags=flags)
+        assert np.array_equal(gb.cpu().numpy(), ow['grad_background']), ('grad_background', tag)
+        for name, g_, w_ in (('grad_vertices', gv, ow['grad_vertices']), ('grad_vertex_colors', gvc, ow['grad_vertex_colors'])):
+            w_ = np.nan_to_num(w_, nan=0.0, posinf=0.0, neginf=0.0)
+            g_ = np.nan_to_num(g_.cpu().numpy(), nan=0.0, posinf=0.0, neginf=0.0)
+            scale = max(1.0, float(np.abs(w_).max()))
+            err = float(np.abs(g_ - w_).max())
+            assert err <= 1e-4 * scale, (name, err, scale, tag)
+        n += 1
+    print('fuzz_parity: %d random cases agree with the oracle in %.0f s' % (n, time.time() - t0))
+
+
+if __name__ == '__main__':
+    main()
