@@ -34,12 +34,20 @@ def main():
         flags = int(rng.choice([0, 0x200, 0x400])) | int(rng.choice([0, 1]))
         os.environ['DIRT_GRAD_TILES_PER_WG'] = str(int(rng.choice([1, 2, 3, 4, 5])))
         b = {k: v[None] for k, v in s.items() if isinstance(v, np.ndarray)}
+        if kind in ('split', 'shared') and rng.random() < 0.4:  # a batch of scenes of the same sizes
+            B = int(rng.integers(2, 4))
+            F = b['faces'].shape[1]
+            bs = scenes.batch_scene(F, H, W, C, [seed + i for i in range(B)], r_lo=0.01, r_hi=0.3, shared=(kind == 'shared'))
+            b = {k: bs[k] for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
         want = oracle.forward(b['background'], b['vertices'], b['vertex_colors'], b['faces'])
-        got = ops._op_rasterise(t(b['background']), t(b['vertices']), t(b['vertex_colors']), t(b['faces']), H, W, C, flags=flags & ~1)
-        tag = (kind, H, W, C, seed, hex(flags), os.environ['DIRT_GRAD_TILES_PER_WG'])
+        use_state = rng.random() < 0.5  # the autograd path: the forward keeps its state, the backward consumes it
+        got = ops._op_rasterise(t(b['background']), t(b['vertices']), t(b['vertex_colors']), t(b['faces']), H, W, C, flags=flags & ~1,
+                                keep_state=use_state)
+        got, state = got if use_state else (got, None)
+        tag = (kind, b['vertices'].shape[0], H, W, C, seed, hex(flags), os.environ['DIRT_GRAD_TILES_PER_WG'], use_state)
         assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), ('forward', tag)
         ow = oracle.backward(b['vertices'], b['faces'], want, b['grad_pixels'], flags=flags & 1)
-        gb, gv, gvc, _ = ops._op_rasterise_grad(t(b['vertices']), t(b['faces']), t(want), t(b['grad_pixels']), H, W, C, flags=flags)
+        gb, gv, gvc, _ = ops._op_rasterise_grad(t(b['vertices']), t(b['faces']), t(want), t(b['grad_pixels']), H, W, C, flags=flags, state=state)
         assert np.array_equal(gb.cpu().numpy(), ow['grad_background']), ('grad_background', tag)
         for name, g_, w_ in (('grad_vertices', gv, ow['grad_vertices']), ('grad_vertex_colors', gvc, ow['grad_vertex_colors'])):
             w_ = np.nan_to_num(w_, nan=0.0, posinf=0.0, neginf=0.0)
