@@ -52,10 +52,19 @@ __device__ inline bool setup_face(const float* __restrict__ verts, int V, const 
                                   int H, int W, FaceRec& rec, FaceBox& box)
 {
     double X[3], Y[3], Wc[3], Z[3];
+    // the three indices, then the three vertices, are requested together (two memory latencies, not six); a bad
+    // index reads vertex 0 instead and drops the face afterwards
+    const int32_t i0 = face[0], i1 = face[1], i2 = face[2];
+    const bool index_ok = ((uint32_t)i0 < (uint32_t)V) & ((uint32_t)i1 < (uint32_t)V) & ((uint32_t)i2 < (uint32_t)V);
+    if (V <= 0) return false;
+    float4 vv[3];
+    vv[0] = *reinterpret_cast<const float4*>(verts + (size_t)((uint32_t)i0 < (uint32_t)V ? i0 : 0) * 4);
+    vv[1] = *reinterpret_cast<const float4*>(verts + (size_t)((uint32_t)i1 < (uint32_t)V ? i1 : 0) * 4);
+    vv[2] = *reinterpret_cast<const float4*>(verts + (size_t)((uint32_t)i2 < (uint32_t)V ? i2 : 0) * 4);
+    if (!index_ok) return false;
     for (int k = 0; k < 3; ++k) {
-        const int32_t vi = face[k];
-        if (vi < 0 || vi >= V) return false;
-        const float4 v = *reinterpret_cast<const float4*>(verts + (size_t)vi * 4);
+        const int32_t vi = k == 0 ? i0 : (k == 1 ? i1 : i2);
+        const float4 v = vv[k];
         if (!(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w))) return false;
         X[k] = ((double)v.x + (double)v.w) * (0.5 * (double)W);
         Y[k] = ((double)v.y + (double)v.w) * (0.5 * (double)H);

@@ -70,12 +70,19 @@ __global__ __launch_bounds__(256) void setup_kernel(GeomParams g)
     // side job: clear the gradient accumulators of the backward pass (the cudaMemsetAsync x4 of
     // csrc/rasterise_grad_egl.cu:244-250) so that no separate launch is needed for it
     {
+        // 16 bytes per store (the buffers are 16-byte aligned and their sizes multiples of 16: [B,V,4] floats and the
+        // 256-byte aligned workspace regions; caller tensors of other sizes get a dword tail)
         const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
         const size_t gtid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid;
-        uint32_t* zb = reinterpret_cast<uint32_t*>(g.zero_b);
-        uint32_t* zc = reinterpret_cast<uint32_t*>(g.zero_c);
-        for (size_t i = gtid; i < g.zero_b_bytes / 4; i += nthreads) zb[i] = 0u;
-        for (size_t i = gtid; i < g.zero_c_bytes / 4; i += nthreads) zc[i] = 0u;
+        uint4* zb = reinterpret_cast<uint4*>(g.zero_b);
+        uint4* zc = reinterpret_cast<uint4*>(g.zero_c);
+        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+        for (size_t i = gtid; i < g.zero_b_bytes / 16; i += nthreads) zb[i] = z4;
+        for (size_t i = gtid; i < g.zero_c_bytes / 16; i += nthreads) zc[i] = z4;
+        uint32_t* tb = reinterpret_cast<uint32_t*>(g.zero_b) + (g.zero_b_bytes / 16) * 4;
+        uint32_t* tc = reinterpret_cast<uint32_t*>(g.zero_c) + (g.zero_c_bytes / 16) * 4;
+        if (gtid < (g.zero_b_bytes % 16) / 4) tb[gtid] = 0u;
+        if (gtid < (g.zero_c_bytes % 16) / 4) tc[gtid] = 0u;
     }
     s_cnt[tid] = 0;
     if (tid == 0) s_cnt[MAX_BINS] = 0;
