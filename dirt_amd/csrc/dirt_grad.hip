@@ -457,7 +457,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         const float4 fh4 = s_frag[py_l][px_l];
 
         // ---- background gradient (:143-147) and colour gradients (:135-142) of the pass's channels ----
-        if (inside) {
+        if (inside && CSPEC) {
             float* gbk = p.grad_background + pix * C + c0;
             if (nch == 4 && (C & 3) == 0 && aligned16) {
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -466,6 +466,19 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
 #pragma unroll
                 for (int c = 0; c < PC; ++c)
                     if (c < nch) gbk[c] = face_here >= 0 ? 0.f : gch[c];
+            }
+        } else if (inside && c0 == 0) {
+            // any channel count: the whole pixel at once in the first pass (zero where covered, grad_pixels where
+            // not), so that a pixel's 4 * C bytes are written once instead of 12 bytes of them in every pass
+            float* gbk = p.grad_background + pix * C;
+            if ((C & 3) == 0 && aligned16) {
+                for (int c = 0; c < C; c += 4) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (face_here < 0) v = *reinterpret_cast<const float4*>(g_here + c);
+                    *reinterpret_cast<float4*>(gbk + c) = v;
+                }
+            } else {
+                for (int c = 0; c < C; ++c) gbk[c] = face_here >= 0 ? 0.f : g_here[c];
             }
         }
         {
