@@ -55,8 +55,8 @@ def kernel_algorithmic_bytes(P, V, F, C):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--scenes-per-gpu', type=int, default=1)
     ap.add_argument('--config', default='K3', help='K3 | K3-256 | K3-2048 | K5')
     ap.add_argument('--no-cpu-baseline', action='store_true')
