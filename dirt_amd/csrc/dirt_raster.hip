@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void setup_kernel(GeomParams g)
 // A tile is 2 x 2 wave regions; a wave region is NB x NB blocks of 8 x 8 pixels (NB * NB pixels per lane).
 // NB = 2 (32 x 32 tiles, one record fetch serves 256 pixels) is the normal shape; NB = 1 (16 x 16 tiles) gives four
 // times as many workgroups for small frames, where 32 x 32 tiles would leave most of the 1024 SIMDs idle.
-constexpr int RTHREADS = 256;     // 4 waves
+constexpr int RTHREADS = 256;     // 4 waves: one per region (NB = 2); NB = 1 tiles use two waves per region (512 threads)
 constexpr int LIST_CAP = 2048;    // bin entries scanned (and at most listed) per round
 
 // What the coverage / depth loop reads per candidate: built once per (tile, candidate) by one lane when the
@@ -334,8 +334,12 @@ __device__ __forceinline__ void shade_pixel(const RasterParams& p, const FaceRec
 }
 
 template <int MODE, int NB, int CSPEC>
-__global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
+__global__ __launch_bounds__(NB == 1 ? 2 * RTHREADS : RTHREADS) void raster_kernel(RasterParams p)
 {
+    // Small tiles exist for frames with few tiles: there the candidates of a region are shared by SPLIT waves (each
+    // takes every SPLIT-th one) whose (z24, face) minima are merged through LDS, which doubles the waves in flight.
+    constexpr int SPLIT = NB == 1 ? 2 : 1;
+    constexpr int RT = RTHREADS * SPLIT;
     constexpr int TILE_W = 16 * NB, TILE_H = 16 * NB;  // pixels
     constexpr int BT = 2 * NB;                         // blocks per tile side: block (bx, by) = mask bit BT * by + bx
     __shared__ int32_t s_face[LIST_CAP];
@@ -345,6 +349,8 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
     __shared__ uint32_t s_run_base[2 * MAX_BINS];      // first entry of each run, relative to the scene's entries
     __shared__ TileRec s_rec[64];          // tile-local records of the 64 list entries being rasterised
     __shared__ int32_t s_vis[TILE_W * TILE_H];  // the tile's visibility, for the row-major resolve
+    __shared__ int32_t s_mf[(SPLIT > 1 ? SPLIT - 1 : 1) * (SPLIT > 1 ? TILE_W * TILE_H : 1)];   // minima of the waves with part > 0
+    __shared__ uint32_t s_mz[(SPLIT > 1 ? SPLIT - 1 : 1) * (SPLIT > 1 ? TILE_W * TILE_H : 1)];
 
 #ifdef DIRT_TRACE
     long long tr_t[8]; int tr_n = 0;
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
     const BinCell* __restrict__ cells = p.cells + (size_t)ib * p.nchunk * (MAX_BINS + 1);
     const BinEntry* __restrict__ scene_entries = p.entries + (size_t)ib * p.nchunk * (5 * (size_t)p.chunk_faces);
     const int nruns = 2 * p.nchunk;
-    for (int j = tid; j < nruns; j += RTHREADS) {
+    for (int j = tid; j < nruns; j += RT) {
         const int c = j < p.nchunk ? j : j - p.nchunk;
         const BinCell cell = cells[(size_t)c * (MAX_BINS + 1) + (j < p.nchunk ? bin : MAX_BINS)];
         s_run_base[j] = (uint32_t)c * (5u * (uint32_t)p.chunk_faces) + cell.start;
@@ -408,7 +414,8 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
     const int n_all = (int)s_pre[nruns];
 
     // this wave's region (blocks NB*wx .. NB*wx + NB-1, NB*wy .. of the tile) and this lane's NB x NB pixels
-    const int wx = wave & 1, wy = wave >> 1;
+    const int region = wave & 3, part = wave >> 2;  // waves r, r + 4, ... take alternate candidates of region r
+    const int wx = region & 1, wy = region >> 1;
     const int x0 = tx0 + wx * (8 * NB) + (lane & 7);
     const int r0 = tr0 + wy * (8 * NB) + (lane >> 3);
     double px[NB], py[NB];
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
         __syncthreads();
         TRACE_MARK();  // 2: first barrier
         const int round_end = min(n_all, round + LIST_CAP);
-        for (int base = round; base < round_end; base += RTHREADS) {
+        for (int base = round; base < round_end; base += RT) {
             const int e = base + tid;
             bool hit = false;
             BinEntry en;
@@ -475,6 +482,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
         // ---- candidates, 64 at a time: one lane per candidate builds its tile-local record in LDS (one
         //      memory latency per chunk instead of one per candidate), then every wave walks the ones that
         //      touch its blocks; with ~64 VGPRs there are enough waves in flight to hide the LDS reads ----
+        uint32_t seen = 0;  // candidates of this region so far (wave-uniform)
         for (int cb = 0; cb < n; cb += 64) {
             const int m_chunk = min(64, n - cb);
             TRACE_ACC(0);
@@ -494,6 +502,11 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
                     mym4 |= ((mk >> ((NB * wy + by) * BT + NB * wx)) & ((1u << NB) - 1u)) << (NB * by);
             }
             unsigned long long m = __builtin_amdgcn_ballot_w64(mym4 != 0);
+            if (SPLIT > 1) {  // this wave's share: the candidates of the region whose running rank is `part` modulo SPLIT
+                const uint32_t rank = seen + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                seen += (uint32_t)__popcll(m);
+                m = __builtin_amdgcn_ballot_w64(mym4 != 0 && (int)(rank % (uint32_t)SPLIT) == part);
+            }
             while (m) {
                 const int k = __ffsll((long long)m) - 1;
                 m &= m - 1;
@@ -513,14 +526,43 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
     // ---- resolve through an LDS visibility tile: the per-lane results are scattered to it, then the 256
     //      threads walk the tile row-major (32 consecutive pixels of a row per half-wave: coalesced HWC
     //      stores) to export visibility and / or shade ----
+    if (SPLIT > 1) {
+        // merge: waves with part > 0 publish their minima, the region's first wave folds them in -- the same
+        // (z24, face) lexicographic minimum; -1 = that wave saw no fragment
+        if (part > 0) {
 #pragma unroll
-    for (int by = 0; by < NB; ++by)
+            for (int k = 0; k < NB * NB; ++k) {
+                const int i = (wy * (8 * NB) + (k / NB) * 8 + (lane >> 3)) * TILE_W + wx * (8 * NB) + (k % NB) * 8 + (lane & 7);
+                s_mf[(part - 1) * TILE_W * TILE_H + i] = fbest[k];
+                s_mz[(part - 1) * TILE_W * TILE_H + i] = zbest[k];
+            }
+        }
+        __syncthreads();
+        if (part == 0) {
 #pragma unroll
-        for (int bx = 0; bx < NB; ++bx)
-            s_vis[(wy * (8 * NB) + by * 8 + (lane >> 3)) * TILE_W + wx * (8 * NB) + bx * 8 + (lane & 7)] = fbest[NB * by + bx];
+            for (int k = 0; k < NB * NB; ++k) {
+                const int i = (wy * (8 * NB) + (k / NB) * 8 + (lane >> 3)) * TILE_W + wx * (8 * NB) + (k % NB) * 8 + (lane & 7);
+#pragma unroll
+                for (int q = 0; q < SPLIT - 1; ++q) {
+                    const int32_t f2 = s_mf[q * TILE_W * TILE_H + i];
+                    const uint32_t z2 = s_mz[q * TILE_W * TILE_H + i];
+                    const bool take = (f2 >= 0) & ((z2 < zbest[k]) | ((z2 == zbest[k]) & (f2 < fbest[k])));
+                    zbest[k] = take ? z2 : zbest[k];
+                    fbest[k] = take ? f2 : fbest[k];
+                }
+            }
+        }
+    }
+    if (part == 0) {
+#pragma unroll
+        for (int by = 0; by < NB; ++by)
+#pragma unroll
+            for (int bx = 0; bx < NB; ++bx)
+                s_vis[(wy * (8 * NB) + by * 8 + (lane >> 3)) * TILE_W + wx * (8 * NB) + bx * 8 + (lane & 7)] = fbest[NB * by + bx];
+    }
     __syncthreads();
 #pragma unroll 1
-    for (int i = tid; i < TILE_W * TILE_H; i += RTHREADS) {
+    for (int i = tid; i < TILE_W * TILE_H; i += RT) {
         const int x = tx0 + (i & (TILE_W - 1)), r = tr0 + i / TILE_W;
         if (r >= p.H || x >= p.W) continue;
         const int32_t f = s_vis[i];
@@ -602,11 +644,11 @@ hipError_t launch_raster(const RasterParams& p_in, int B, bool visibility_only, 
     const int cspec = visibility_only ? 0 : (p.C == 4 ? 4 : (p.C == 3 ? 3 : (p.C == 1 ? 1 : 0)));
 #define DIRT_LAUNCH_RASTER(NB_)                                                                               \
     do {                                                                                                      \
-        if (visibility_only) hipLaunchKernelGGL((raster_kernel<1, NB_, 0>), grid, dim3(RTHREADS), 0, stream, p);   \
-        else if (cspec == 4) hipLaunchKernelGGL((raster_kernel<0, NB_, 4>), grid, dim3(RTHREADS), 0, stream, p);   \
-        else if (cspec == 3) hipLaunchKernelGGL((raster_kernel<0, NB_, 3>), grid, dim3(RTHREADS), 0, stream, p);   \
-        else if (cspec == 1) hipLaunchKernelGGL((raster_kernel<0, NB_, 1>), grid, dim3(RTHREADS), 0, stream, p);   \
-        else hipLaunchKernelGGL((raster_kernel<0, NB_, 0>), grid, dim3(RTHREADS), 0, stream, p);                   \
+        if (visibility_only) hipLaunchKernelGGL((raster_kernel<1, NB_, 0>), grid, dim3(NB_ == 1 ? 2 * RTHREADS : RTHREADS), 0, stream, p);   \
+        else if (cspec == 4) hipLaunchKernelGGL((raster_kernel<0, NB_, 4>), grid, dim3(NB_ == 1 ? 2 * RTHREADS : RTHREADS), 0, stream, p);   \
+        else if (cspec == 3) hipLaunchKernelGGL((raster_kernel<0, NB_, 3>), grid, dim3(NB_ == 1 ? 2 * RTHREADS : RTHREADS), 0, stream, p);   \
+        else if (cspec == 1) hipLaunchKernelGGL((raster_kernel<0, NB_, 1>), grid, dim3(NB_ == 1 ? 2 * RTHREADS : RTHREADS), 0, stream, p);   \
+        else hipLaunchKernelGGL((raster_kernel<0, NB_, 0>), grid, dim3(NB_ == 1 ? 2 * RTHREADS : RTHREADS), 0, stream, p);                   \
     } while (0)
     if (tile == 32) DIRT_LAUNCH_RASTER(2);
     else DIRT_LAUNCH_RASTER(1);
