@@ -1,7 +1,7 @@
 """Randomised parity sweep on an MI355X box: random frame sizes, channel counts, meshes (split / shared / hostile),
 kernel tile shapes, tiles per workgroup and flags; every case compares the HIP path with the CPU oracle (forward
-and visibility bit for bit, gradients within 1e-4 of the tensor scale).  Not part of the test suite (open-ended);
-usage: python tools/fuzz_parity.py [seconds] [seed]"""
+and visibility bit for bit, gradients within 1e-4 of the tensor scale).  Not collected by pytest (open-ended: runs for a time budget);
+usage: python tests/fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
 import time
