@@ -220,9 +220,10 @@ __device__ __forceinline__ float2 scharr_taps_wrapped(const float* __restrict__ 
     return make_float2(sx, sy);
 }
 
-template <int GH, int COPIES, int CSPEC>
-__global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(GradParams p)
+template <int GH, int COPIES, int CSPEC, int SLOTS = 64>
+__global__ __launch_bounds__(GW * GH, SLOTS == 32 ? 6 : GRAD_WAVES_PER_SIMD) void grad_kernel(GradParams p)
 {
+    constexpr int MAX_SLOTS = SLOTS;  // shadows the namespace constant
     constexpr int GTHREADS = GW * GH;  // GH / 8 x 4 waves, one 8 x 8 block each
     constexpr int PH = GH + 2;         // staged rows: y0-1 .. y0+GH
     __shared__ float s_pix[PC][PH][PW];                              // the pass's channels of `pixels`, edge clamped
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
         if (c0 == 0 && wave == 0) {
             // the slot table is complete: list the occupied slots for the flush (typically ~20 of 64); read after the
             // barrier that separates accumulation from flush
-            const bool used = s_key[lane] >= 0;  // MAX_SLOTS == 64 == one wave
+            const bool used = lane < MAX_SLOTS && s_key[lane & (MAX_SLOTS - 1)] >= 0;
             const unsigned long long um = __builtin_amdgcn_ballot_w64(used);
             if (used) s_used[__popcll(um & ((1ull << lane) - 1ull))] = (uint8_t)lane;
             if (lane == 0) s_nused = __popcll(um);
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(GW * GH, GRAD_WAVES_PER_SIMD) void grad_kernel(Grad
     __syncthreads();
     GMARK();  // 1 init
     for (int t = (int)blockIdx.x;;) {
-        const int tn = (CSPEC && t + (int)gridDim.x < ntiles) ? t + (int)gridDim.x : -1;
+        const int tn = (CSPEC && SLOTS == 64 && t + (int)gridDim.x < ntiles) ? t + (int)gridDim.x : -1;
         process_tile(t, cur, tn, nxt);
         if (tn < 0) break;
         cur = nxt;
@@ -751,17 +752,31 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
             if (v >= 1) tiles_per_wg = v;
         }
     }
-    const dim3 grid((unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg), (unsigned)p.B);
-#define DIRT_LAUNCH_GRAD(GH_, CP_)                                                                          \
-    do {                                                                                                    \
-        const dim3 block(GW * GH_);                                                                         \
-        if (cspec == 4) hipLaunchKernelGGL((grad_kernel<GH_, CP_, 4>), grid, block, 0, stream, p);          \
-        else if (cspec == 3) hipLaunchKernelGGL((grad_kernel<GH_, CP_, 3>), grid, block, 0, stream, p);     \
-        else if (cspec == 1) hipLaunchKernelGGL((grad_kernel<GH_, CP_, 1>), grid, block, 0, stream, p);     \
-        else hipLaunchKernelGGL((grad_kernel<GH_, CP_, 0>), grid, block, 0, stream, p);                     \
+    dim3 grid((unsigned)((ntiles + tiles_per_wg - 1) / tiles_per_wg), (unsigned)p.B);
+    // The channel-specialised 32 x 16 kernels exist with a 64-slot table (two workgroups per CU, next-tile prefetch) and
+    // with a 32-slot table (50 KB of LDS and no prefetch registers: three workgroups per CU, 6 waves per SIMD) for
+    // meshes whose tiles see few faces; a tile that overflows its table is still correct, only slower.
+    int slots = (cspec && gh == 16 && faces_per_tile <= 10.0) ? 32 : 64;
+    if (const char* env = getenv("DIRT_GRAD_SLOTS")) {  // tests pin it
+        const int v = atoi(env);
+        if ((v == 32 && cspec && gh == 16) || v == 64) slots = v;
+    }
+#define DIRT_LAUNCH_GRAD(GH_, CP_, SL_)                                                                          \
+    do {                                                                                                         \
+        const dim3 block(GW * GH_);                                                                              \
+        if (cspec == 4) hipLaunchKernelGGL((grad_kernel<GH_, CP_, 4, SL_>), grid, block, 0, stream, p);          \
+        else if (cspec == 3) hipLaunchKernelGGL((grad_kernel<GH_, CP_, 3, SL_>), grid, block, 0, stream, p);     \
+        else if (cspec == 1) hipLaunchKernelGGL((grad_kernel<GH_, CP_, 1, SL_>), grid, block, 0, stream, p);     \
+        else hipLaunchKernelGGL((grad_kernel<GH_, CP_, 0, 64>), grid, block, 0, stream, p);                      \
     } while (0)
-    if (gh == 16) DIRT_LAUNCH_GRAD(16, 4);
-    else DIRT_LAUNCH_GRAD(8, 2);
+    if (gh == 16 && slots == 32) {
+        grid = dim3((unsigned)ntiles, (unsigned)p.B);  // one tile per workgroup
+        DIRT_LAUNCH_GRAD(16, 4, 32);
+    } else if (gh == 16) {
+        DIRT_LAUNCH_GRAD(16, 4, 64);
+    } else {
+        DIRT_LAUNCH_GRAD(8, 2, 64);
+    }
 #undef DIRT_LAUNCH_GRAD
     return hipGetLastError();
 }

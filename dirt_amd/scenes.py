@@ -89,6 +89,7 @@ CONFIGS = {
     'K3-256': (10000, 256, 256, 4, 0, 0.005, 0.04),
     'K3-2048': (10000, 2048, 2048, 4, 0, 0.005, 0.04),
     'K5': (50000, 2048, 2048, 16, 1, 0.002, 0.018),
+    'K5-3ch': (50000, 2048, 2048, 3, 1, 0.002, 0.018),   # K5's mesh with an RGB image (what deferred shading filters)
 }
 
 

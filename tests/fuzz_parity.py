@@ -33,6 +33,7 @@ def main():
             s = scenes.rand_scene(int(rng.integers(1, 3000)), H, W, C, seed, float(rng.uniform(0.005, 0.1)), float(rng.uniform(0.1, 0.8)), kind == 'shared')
         flags = int(rng.choice([0, 0x200, 0x400])) | int(rng.choice([0, 1]))
         os.environ['DIRT_GRAD_TILES_PER_WG'] = str(int(rng.choice([1, 2, 3, 4, 5])))
+        os.environ['DIRT_GRAD_SLOTS'] = str(int(rng.choice([32, 64])))
         b = {k: v[None] for k, v in s.items() if isinstance(v, np.ndarray)}
         if kind in ('split', 'shared') and rng.random() < 0.4:  # a batch of scenes of the same sizes
             B = int(rng.integers(2, 4))

@@ -278,3 +278,22 @@ def test_several_gradient_tiles_per_workgroup(gpu, oracle, monkeypatch, tiles_pe
         assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
         _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
         _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
+
+
+@pytest.mark.parametrize('slots', ['32', '64'])
+@pytest.mark.parametrize('C', [1, 3, 4])
+def test_gradient_slot_table_sizes(gpu, oracle, monkeypatch, slots, C):
+    """The channel-specialised 32x16 gradient kernels come with a 64-slot and a 32-slot face table (the latter leaves
+    LDS for a third workgroup per CU); pinned here, on a mesh whose tiles see a few faces and on one whose tiles
+    overflow 32 slots (those faces take the direct-atomic path)."""
+    monkeypatch.setenv('DIRT_GRAD_SLOTS', slots)
+    for F, r_lo, r_hi in ((150, 0.1, 0.5), (2500, 0.01, 0.06)):
+        H, W = 96, 128
+        s = _batched(scenes.rand_scene(F, H, W, C, 71, r_lo, r_hi))
+        want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
+        ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'])
+        gb, gv, gvc, _ = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
+                                                _t(s['grad_pixels'], gpu), H, W, C, flags=0x200)
+        assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
+        _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
+        _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
