@@ -64,7 +64,7 @@ constexpr int NVAL = 9 + 3 * PC;       // 9 position values (3 vertices x {x,y,w
 #define GRAD_WAVES_PER_SIMD 4
 #endif
 static_assert(MAX_SLOTS == 64, "the slot bookkeeping uses one wave for the table");
-constexpr int FIX_BITS = 29;           // fixed-point contributions: |q| < 2^FIX_BITS given the tile bound
+constexpr int FIX_BITS = 32;           // fixed-point contributions: |q| <= 2^(FIX_BITS-2) (the bounds carry 2x slack), an int32
 
 __device__ __forceinline__ float quad_sum(float v)
 {
@@ -136,8 +136,9 @@ __device__ __forceinline__ float quad_reduce(const Target& t, float v)
     return t.uniform ? q : v;
 }
 
-// Power-of-two scale for fixed-point accumulation: contributions are bounded by `bound` (> 0,
-// finite), so |v * to_fix| < 2^FIX_BITS.
+// Power-of-two scale for fixed-point accumulation.  `bound` (> 0, finite) is TWICE a rigorous bound on the quad-summed
+// contributions, so |v * to_fix| < 2^(FIX_BITS - 2) = 2^30: an int32 with a bit to spare, at the finest resolution the
+// one-instruction float -> int32 conversion allows.
 struct FixScale {
     float to_fix;    // 2^(FIX_BITS - 1 - E), E = exponent of the bound
     float from_fix;  // its inverse
