@@ -1,7 +1,7 @@
 """Randomised parity sweep on an MI355X box: random frame sizes, channel counts, meshes (split / shared / hostile),
 kernel tile shapes, tiles per workgroup and flags; every case compares the HIP path with the CPU oracle (forward
 and visibility bit for bit, gradients within 1e-4 of the tensor scale).  Not collected by pytest (open-ended: runs for a time budget);
-usage: python tests/fuzz_parity.py [seconds] [seed]"""
+usage: python tests/fuzz_parity.py [seconds] [seed] [hostile]   (`hostile`: mostly hostile geometry, larger frames)"""
 import os
 import sys
 import time
@@ -17,13 +17,14 @@ from dirt_amd import scenes, rasterise_ops as ops  # noqa: E402
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    hard = len(sys.argv) > 3 and sys.argv[3] == 'hostile'
     dev = torch.device('cuda', 0)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     t0, n = time.time(), 0
     while time.time() - t0 < budget:
-        H, W = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        H, W = int(rng.integers(1, 700 if hard else 400)), int(rng.integers(1, 700 if hard else 400))
         C = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 10]))
-        kind = rng.choice(['split', 'shared', 'hostile', 'tiny'])
+        kind = rng.choice(['split', 'shared', 'hostile', 'tiny'], p=[0.1, 0.1, 0.7, 0.1] if hard else None)
         seed = int(rng.integers(0, 1 << 30))
         if kind == 'hostile':
             s = scenes.hostile_scene(H, W, C, seed, int(rng.integers(10, 1500)))
