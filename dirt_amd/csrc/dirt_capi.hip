@@ -81,11 +81,11 @@ void drain_profile()
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
-    size_t recs_off, boxes_off, cells_off, entries_off, vis_off, frag_off, gv_off, gvc_off, total;
+    size_t recs_off, boxes_off, cells_off, entries_off, state_off, gv_off, gvc_off, total;
 };
 
 // Layout: [FaceRec x B*F | FaceBox x B*F | chunk x bin directory | per-chunk BinEntry segments (5 per face) |
-//          int32 visibility x B*H*W | float4 fragments x B*H*W | float grad_vertices x B*V*4 |
+//          float4 per-pixel state {b0, b1, clip_w, face} x B*H*W | float grad_vertices x B*V*4 |
 //          float grad_vertex_colors x B*V*C]
 Workspace carve(int B, int V, int F, int H, int W, int C)
 {
@@ -97,8 +97,7 @@ Workspace carve(int B, int V, int F, int H, int W, int C)
     dirt::chunking(F, nchunk, chunk_faces);
     w.cells_off = off;   off = align_up(off + (size_t)B * nchunk * (dirt::MAX_BINS + 1) * sizeof(dirt::BinCell), 256);
     w.entries_off = off; off = align_up(off + (size_t)B * nchunk * 5 * (size_t)chunk_faces * sizeof(dirt::BinEntry), 256);
-    w.vis_off = off;     off = align_up(off + (size_t)B * H * W * sizeof(int32_t), 256);
-    w.frag_off = off;    off = align_up(off + (size_t)B * H * W * sizeof(float4), 256);
+    w.state_off = off;   off = align_up(off + (size_t)B * H * W * sizeof(float4), 256);
     // gradient accumulators of the backward pass, pre-cleared by a KEEP_STATE forward (dirt_state_grad_buffers)
     w.gv_off = off;      off = align_up(off + (size_t)B * V * 4 * sizeof(float), 256);
     w.gvc_off = off;     off = align_up(off + (size_t)B * V * C * sizeof(float), 256);
@@ -111,8 +110,7 @@ struct Carved {
     dirt::FaceBox* boxes;
     dirt::BinCell* cells;
     dirt::BinEntry* entries;
-    int32_t* vis;
-    float4* frag;
+    float4* state;
     float* gv;
     float* gvc;
 };
@@ -169,8 +167,7 @@ Carved carved(void* workspace, const Workspace& w)
     c.boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
     c.cells = reinterpret_cast<dirt::BinCell*>(ws + w.cells_off);
     c.entries = reinterpret_cast<dirt::BinEntry*>(ws + w.entries_off);
-    c.vis = reinterpret_cast<int32_t*>(ws + w.vis_off);
-    c.frag = reinterpret_cast<float4*>(ws + w.frag_off);
+    c.state = reinterpret_cast<float4*>(ws + w.state_off);
     c.gv = reinterpret_cast<float*>(ws + w.gv_off);
     c.gvc = reinterpret_cast<float*>(ws + w.gvc_off);
     return c;
@@ -195,7 +192,7 @@ dirt::RasterParams raster_params(const Carved& c, const dirt::GeomParams& g, int
     dirt::RasterParams p;
     p.flags = flags;
     p.recs = c.recs; p.cells = c.cells; p.entries = c.entries; p.nchunk = g.nchunk; p.chunk_faces = g.chunk_faces;
-    p.background = nullptr; p.vertex_colors = nullptr; p.pixels = nullptr; p.vis = nullptr; p.frag = nullptr;
+    p.background = nullptr; p.vertex_colors = nullptr; p.pixels = nullptr; p.vis = nullptr; p.state = nullptr;
     p.V = g.V; p.F = g.F; p.H = g.H; p.W = g.W; p.C = C;
     p.grid = g.grid; p.tiles_x = 0; p.tiles_y = 0;
     return p;
@@ -245,7 +242,7 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
     }
     dirt::RasterParams p = raster_params(c, g, C, flags);
     p.background = background; p.vertex_colors = vertex_colors; p.pixels = pixels;
-    if (flags & DIRT_FLAG_KEEP_STATE) { p.vis = c.vis; p.frag = c.frag; }  // the records already live in the workspace
+    if (flags & DIRT_FLAG_KEEP_STATE) p.state = c.state;
     {
         Scope sc(prof, SLOT_RASTER_FWD, stream);
         HIP_TRY(who, dirt::launch_raster(p, B, false, stream));
@@ -330,17 +327,15 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
             HIP_TRY(who, dirt::launch_geometry(g, stream));
         }
         dirt::RasterParams rp = raster_params(c, g, C, flags);
-        rp.vis = c.vis; rp.frag = c.frag;
+        rp.state = c.state;
         {
             Scope sc(prof, SLOT_RASTER_VIS, stream);
             HIP_TRY(who, dirt::launch_raster(rp, B, true, stream));
         }
     }
-    int32_t* vis = c.vis;
-    auto* recs = c.recs;
-
     dirt::GradParams gp;
-    gp.recs = recs; gp.vis = vis; gp.frag = c.frag; gp.vertices = vertices; gp.pixels = pixels; gp.grad_pixels = grad_pixels;
+    gp.state = c.state; gp.faces = faces; gp.shared_faces = (flags & DIRT_FLAG_SHARED_FACES) ? 1 : 0;
+    gp.pixels = pixels; gp.grad_pixels = grad_pixels;
     gp.grad_background = grad_background; gp.grad_vertices = grad_vertices;
     gp.grad_vertex_colors = grad_vertex_colors; gp.debug_thingy = debug_thingy;
     gp.B = B; gp.V = V; gp.F = F; gp.H = H; gp.W = W; gp.C = C; gp.flags = flags;

@@ -8,7 +8,7 @@ namespace dirt {
 
 constexpr int MAX_BINS = 256;
 
-// Coarse binning grid: square bins of (1 << shift) pixels, shift >= 7, bins_x * bins_y <= MAX_BINS.
+// Coarse binning grid: square bins of (1 << shift) pixels, shift >= 5, bins_x * bins_y <= MAX_BINS.
 struct BinGrid {
     int shift, bins_x, bins_y;
 };
@@ -53,8 +53,8 @@ struct RasterParams {
     const float* background;     // [B,H,W,C]
     const float* vertex_colors;  // [B,V,C]
     float* pixels;               // [B,H,W,C]
-    int32_t* vis;                // [B,H,W] visibility export (MODE 1; optional in MODE 0)
-    float4* frag;                // [B,H,W] (b0,b1,b2,clip_w) of the front-most fragment, exported with vis for the backward pass; or nullptr
+    int32_t* vis;                // [B,H,W] front-most face per pixel (dirt_rasterise_visibility's output); or nullptr
+    float4* state;               // [B,H,W] {b0, b1, clip_w, face} of the front-most fragment: what the backward pass reads; or nullptr
     int V, F, H, W, C;
     BinGrid grid;
     unsigned flags;              // DIRT_FLAG_TILES_*
@@ -62,10 +62,10 @@ struct RasterParams {
 };
 
 struct GradParams {
-    const FaceRec* recs;       // [B*F]
-    const int32_t* vis;        // [B,H,W] front-most face or -1
-    const float4* frag;        // [B,H,W] its (b0,b1,b2,clip_w): the backward fragment shader's output, csrc/shaders.cpp:64-77
-    const float* vertices;     // [B,V,4]
+    const float4* state;       // [B,H,W] {b0, b1, clip_w, face}: the backward fragment shader's output (csrc/shaders.cpp:64-77)
+                               //         with b2 = 1 - b0 - b1 and the face index (bit pattern) in place of the index triple
+    const int32_t* faces;      // [B,F,3], or [F,3] when shared_faces
+    int shared_faces;
     const float* pixels;       // [B,H,W,C]
     const float* grad_pixels;  // [B,H,W,C]
     float* grad_background;    // [B,H,W,C]
@@ -75,7 +75,7 @@ struct GradParams {
     int B, V, F, H, W, C;
     unsigned flags;
     int tiles_x, tiles_y;      // filled by launch_grad
-    int pixels_aligned16;      // `pixels` may be read with 16-byte loads, filled by launch_grad
+    int pixels_aligned16;      // the [B,H,W,C] tensors may be accessed with 16-byte loads / stores, filled by launch_grad
 };
 
 BinGrid make_bin_grid(int H, int W);

@@ -33,7 +33,7 @@ __device__ long long* g_trace_buf = nullptr;
 #endif
 
 // ---- binning ---------------------------------------------------------------------------------
-// The frame is cut into at most MAX_BINS square bins of 2^shift pixels (>= 128, so a raster tile never
+// The frame is cut into at most MAX_BINS square bins of 2^shift pixels (>= 32, so a raster tile never
 // straddles two bins).  ONE kernel builds, per scene, exact-size lists of the faces touching each bin -- the
 // replacement for the GL driver's own binning hardware -- without a single global atomic, without any
 // buffer that needs clearing and without any cross-workgroup dependency:
@@ -265,11 +265,14 @@ __device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec
     }
 }
 
-// The backward pass's fragment of one pixel, (b0, b1, b2, clip_w): csrc/shaders.cpp:64-77.
-__device__ __forceinline__ void export_frag(const RasterParams& p, const FaceRec* __restrict__ recs, int ib, int x, int r,
-                                            double px, double py, int32_t f)
+// The backward pass's state of one pixel, {b0, b1, clip_w, face}: csrc/shaders.cpp:64-77 (b2 = 1 - b0 - b1; the face
+// index stands for the index triple); the clear values of csrc/rasterise_grad_egl.cpp:442-445 where nothing is covered.
+__device__ __forceinline__ float4 state_clear() { return make_float4(-1.f, -1.f, INFINITY, __int_as_float(-1)); }
+
+__device__ __forceinline__ void export_state(const RasterParams& p, const FaceRec* __restrict__ recs, int ib, int x, int r,
+                                             double px, double py, int32_t f)
 {
-    float4 fr = make_float4(-1.f, -1.f, -1.f, INFINITY);
+    float4 st = state_clear();
     if (f >= 0) {
         const FaceRec* __restrict__ rec = recs + f;
         double cf[9];
@@ -279,9 +282,9 @@ __device__ __forceinline__ void export_frag(const RasterParams& p, const FaceRec
         edge_eval(cf, px, py, Fk);
         float b[3], cw;
         bary_eval(Fk, rec->flags, rec->inv_det, b, cw);
-        fr = make_float4(b[0], b[1], b[2], cw);
+        st = make_float4(b[0], b[1], cw, __int_as_float(f));
     }
-    p.frag[((size_t)ib * p.H + r) * p.W + x] = fr;
+    p.state[((size_t)ib * p.H + r) * p.W + x] = st;
 }
 
 // Shade one pixel: the winner's record is re-read, barycentrics and all C channels interpolated once.
@@ -293,7 +296,7 @@ __device__ __forceinline__ void shade_pixel(const RasterParams& p, const FaceRec
     const int C = CSPEC ? CSPEC : p.C;  // CSPEC = 1, 3, 4: compile-time channel count; 0: any
     float* __restrict__ out = p.pixels + pix * C;
     if (f < 0) {  // pixels start as the background: csrc/rasterise_egl.cpp:348-356
-        if (p.frag) p.frag[pix] = make_float4(-1.f, -1.f, -1.f, INFINITY);  // clear values, csrc/rasterise_grad_egl.cpp:442-445
+        if (p.state) p.state[pix] = state_clear();
         const float* __restrict__ bg = p.background + pix * C;
         if ((C & 3) == 0) {
             for (int c = 0; c < C; c += 4)
@@ -311,7 +314,7 @@ __device__ __forceinline__ void shade_pixel(const RasterParams& p, const FaceRec
     edge_eval(cf, px, py, Fk);
     float b[3], cw;
     bary_eval(Fk, rec->flags, rec->inv_det, b, cw);
-    if (p.frag) p.frag[pix] = make_float4(b[0], b[1], b[2], cw);
+    if (p.state) p.state[pix] = make_float4(b[0], b[1], cw, __int_as_float(f));
     const float* __restrict__ cols = p.vertex_colors + (size_t)ib * p.V * C;
     const float* __restrict__ c0 = cols + (size_t)rec->vid[0] * C;
     const float* __restrict__ c1 = cols + (size_t)rec->vid[1] * C;
@@ -566,9 +569,9 @@ __global__ __launch_bounds__(NB == 1 ? 2 * RTHREADS : RTHREADS) void raster_kern
         const int x = tx0 + (i & (TILE_W - 1)), r = tr0 + i / TILE_W;
         if (r >= p.H || x >= p.W) continue;
         const int32_t f = s_vis[i];
-        if (MODE == 1 || p.vis) p.vis[((size_t)ib * p.H + r) * p.W + x] = f;
+        if (p.vis) p.vis[((size_t)ib * p.H + r) * p.W + x] = f;
         if (MODE == 0) shade_pixel<CSPEC>(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
-        else if (p.frag) export_frag(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
+        else if (p.state) export_state(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
     }
     TRACE_MARK();  // 7: stored
 #ifdef DIRT_TRACE

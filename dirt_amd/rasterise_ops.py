@@ -100,6 +100,16 @@ def _require_gpu(*tensors):
     return dev
 
 
+def _dense16(t):
+    """A dense tensor whose storage the kernels may access with 16-byte loads: `.contiguous()` returns contiguous
+    views unchanged, and a view such as `x[1:]` of a 5x5x3 frame starts at an address that is not a multiple of 16
+    (the C ABI rejects those); the reference accepts any tensor, so such views are copied."""
+    t = t.contiguous()
+    if t.data_ptr() % 16 != 0:
+        t = t.clone(memory_format=torch.contiguous_format)
+    return t
+
+
 def _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels, flags=0, keep_state=False,
                   state_channels=0):
     """`_rasterise_module.rasterise` (dirt/rasterise_ops.py:81-85): the raw forward op, no autograd.
@@ -112,7 +122,7 @@ def _op_rasterise(background, vertices, vertex_colors, faces, height, width, cha
     lib = _lib.load()
     _check_forward_shapes(background, vertices, vertex_colors, faces, height, width, channels)
     dev = _require_gpu(background, vertices, vertex_colors, faces)
-    background, vertices, vertex_colors, faces = (t.contiguous() for t in (background, vertices, vertex_colors, faces))
+    background, vertices, vertex_colors, faces = (_dense16(t) for t in (background, vertices, vertex_colors, faces))
     B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[-2]
     if faces.dim() == 2:
         flags |= _lib.FLAG_SHARED_FACES
@@ -149,7 +159,7 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
     if tuple(pixels.shape[1:]) != (height, width, channels):
         raise ValueError('RasteriseGrad expects pixels to be 4D, and pixels.shape == [None, height, width, channels]')
     dev = _require_gpu(vertices, faces, pixels, grad_pixels)
-    vertices, faces, pixels, grad_pixels = (t.contiguous() for t in (vertices, faces, pixels, grad_pixels))
+    vertices, faces, pixels, grad_pixels = (_dense16(t) for t in (vertices, faces, pixels, grad_pixels))
     B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[-2]
     if faces.dim() == 2:
         flags |= _lib.FLAG_SHARED_FACES
@@ -194,7 +204,7 @@ def _op_visibility(vertices, faces, height, width):
     """Front-most face per pixel, [B,H,W] int32 (-1 = background)."""
     lib = _lib.load()
     dev = _require_gpu(vertices, faces)
-    vertices, faces = vertices.contiguous(), faces.contiguous()
+    vertices, faces = _dense16(vertices), _dense16(faces)
     B, V, F = vertices.shape[0], vertices.shape[1], faces.shape[-2]
     flags = _lib.FLAG_SHARED_FACES if faces.dim() == 2 else 0
     face_id = torch.empty((B, height, width), dtype=torch.int32, device=dev)
@@ -223,11 +233,19 @@ class _Rasterise(torch.autograd.Function):
         return pixels
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_pixels):
         vertices, faces, pixels = ctx.saved_tensors
         height, width, channels = ctx.hwc
+        # The first backward accumulates into the buffers the forward pass pre-cleared inside the state (no clearing
+        # launch) and returns views of them.  A later backward over the same forward (retain_graph=True, per-loss
+        # autograd.grad, Jacobian loops) must neither add onto those nor alias them: it gets fresh, cleared outputs --
+        # the reference's grad op is pure (csrc/rasterise_grad_egl.cu:244-250 clears its outputs on every call).
+        first = not getattr(ctx, 'state_outputs_used', False)
+        ctx.state_outputs_used = True
         grad_background, grad_vertices, grad_vertex_colors, _ = _op_rasterise_grad(
-            vertices, faces, pixels, grad_pixels.to(torch.float32), height, width, channels, state=ctx.state)
+            vertices, faces, pixels, grad_pixels.to(torch.float32), height, width, channels, state=ctx.state,
+            state_outputs=first)
         return grad_background, grad_vertices, grad_vertex_colors, None, None, None, None  # None wrt faces
 
 
@@ -322,6 +340,7 @@ class _RasteriseDeferred(torch.autograd.Function):
         return pixels.detach()
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, d_loss_by_pixels):
         vertices, faces = ctx.saved_tensors
         gbuffer_in, extra_in, pixels, shader_params = ctx.graph
@@ -332,7 +351,11 @@ class _RasteriseDeferred(torch.autograd.Function):
         # backprop through shader_fn to the G-buffer (dirt/rasterise_ops.py:212-229)
         diff_extra = [t for t in extra_in if isinstance(t, torch.Tensor) and t.requires_grad]
         diff_params = [t for t in shader_params if isinstance(t, torch.Tensor) and t.requires_grad]
-        grads = torch.autograd.grad(pixels, [gbuffer_in] + diff_extra + diff_params, d_loss_by_pixels, allow_unused=True)
+        if pixels.requires_grad:
+            grads = torch.autograd.grad(pixels, [gbuffer_in] + diff_extra + diff_params, d_loss_by_pixels, allow_unused=True,
+                                        retain_graph=True)  # the node may be differentiated again (retain_graph=True upstream)
+        else:  # a shader that does not depend on any differentiable input
+            grads = [None] * (1 + len(diff_extra) + len(diff_params))
         d_loss_by_gbuffer = grads[0]
         if d_loss_by_gbuffer is None:
             d_loss_by_gbuffer = torch.zeros_like(gbuffer_in)

@@ -50,15 +50,19 @@ def gather_batch(local, n_scenes, dst=0, group=None):
     return out
 
 
-def rasterise_batch_sharded(background, vertices, vertex_colors, faces, group=None, gather=False):
+def rasterise_batch_sharded(background, vertices, vertex_colors, faces, group=None, gather=False, rank=None, world_size=None):
     """Render this rank's share of a replicated batch.  Returns the local pixels [n_local,H,W,C]
-    (or, with gather=True, the full batch on rank 0 and None elsewhere)."""
+    (or, with gather=True, the full batch on rank 0 and None elsewhere).  `faces` may be [n_scenes,F,3] (sharded like
+    the other inputs) or one [F,3] topology shared by every scene (handed on unchanged).  `rank` / `world_size`
+    default to the process group's; given explicitly they select the share without any process group (tests)."""
     from .rasterise_ops import rasterise_batch
-    if dist.is_available() and dist.is_initialized():
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-    else:
-        world, rank = 1, 0
+    if rank is None or world_size is None:
+        if dist.is_available() and dist.is_initialized():
+            world_size, rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            world_size, rank = 1, 0
     n = background.shape[0]
-    local = rasterise_batch(shard_batch(background, rank, world), shard_batch(vertices, rank, world),
-                            shard_batch(vertex_colors, rank, world), shard_batch(faces, rank, world))
+    local_faces = shard_batch(faces, rank, world_size) if faces.dim() == 3 else faces
+    local = rasterise_batch(shard_batch(background, rank, world_size), shard_batch(vertices, rank, world_size),
+                            shard_batch(vertex_colors, rank, world_size), local_faces)
     return gather_batch(local, n, 0, group) if gather else local

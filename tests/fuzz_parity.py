@@ -1,5 +1,5 @@
 """Randomised parity sweep on an MI355X box: random frame sizes, channel counts, meshes (split / shared / hostile),
-kernel tile shapes, tiles per workgroup and flags; every case compares the HIP path with the CPU oracle (forward
+kernel tile shapes and flags; every case compares the HIP path with the CPU oracle (forward
 and visibility bit for bit, gradients within 1e-4 of the tensor scale).  Not collected by pytest (open-ended: runs for a time budget);
 usage: python tests/fuzz_parity.py [seconds] [seed] [hostile]   (`hostile`: mostly hostile geometry, larger frames)"""
 import os
@@ -33,8 +33,6 @@ def main():
         else:
             s = scenes.rand_scene(int(rng.integers(1, 3000)), H, W, C, seed, float(rng.uniform(0.005, 0.1)), float(rng.uniform(0.1, 0.8)), kind == 'shared')
         flags = int(rng.choice([0, 0x200, 0x400])) | int(rng.choice([0, 1]))
-        os.environ['DIRT_GRAD_TILES_PER_WG'] = str(int(rng.choice([1, 2, 3, 4, 5])))
-        os.environ['DIRT_GRAD_SLOTS'] = str(int(rng.choice([32, 64])))
         b = {k: v[None] for k, v in s.items() if isinstance(v, np.ndarray)}
         if kind in ('split', 'shared') and rng.random() < 0.4:  # a batch of scenes of the same sizes
             B = int(rng.integers(2, 4))
@@ -46,7 +44,7 @@ def main():
         got = ops._op_rasterise(t(b['background']), t(b['vertices']), t(b['vertex_colors']), t(b['faces']), H, W, C, flags=flags & ~1,
                                 keep_state=use_state)
         got, state = got if use_state else (got, None)
-        tag = (kind, b['vertices'].shape[0], H, W, C, seed, hex(flags), os.environ['DIRT_GRAD_TILES_PER_WG'], use_state)
+        tag = (kind, b['vertices'].shape[0], H, W, C, seed, hex(flags), use_state)
         assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), ('forward', tag)
         ow = oracle.backward(b['vertices'], b['faces'], want, b['grad_pixels'], flags=flags & 1)
         gb, gv, gvc, _ = ops._op_rasterise_grad(t(b['vertices']), t(b['faces']), t(want), t(b['grad_pixels']), H, W, C, flags=flags, state=state)

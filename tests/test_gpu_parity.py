@@ -261,39 +261,112 @@ def test_maximum_frame_dimension(gpu, oracle, H, W):
     _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
 
 
-@pytest.mark.parametrize('tiles_per_wg', ['1', '2', '3', '7'])
-@pytest.mark.parametrize('C', [1, 3, 4])
-def test_several_gradient_tiles_per_workgroup(gpu, oracle, monkeypatch, tiles_per_wg, C):
-    """The channel-specialised gradient kernels walk several tiles per workgroup on large frames (the next tile's
-    inputs are requested while the current one is computed); pinned here on a small frame, including a count that
-    does not divide the number of tiles."""
-    monkeypatch.setenv('DIRT_GRAD_TILES_PER_WG', tiles_per_wg)
-    H, W = 100, 150
-    s = _batched(scenes.rand_scene(700, H, W, C, 61, 0.02, 0.2))
+@pytest.mark.parametrize('C', [1, 3, 4, 6])
+def test_many_dilated_pairs_per_wave(gpu, oracle, C):
+    """The gradient kernel lists the dilated (pixel, channel group) pairs of a wave -- which take a neighbour's face
+    and barycentrics -- in LDS, 27 to 64 of them depending on the channel count; beyond that they take direct float
+    atomics.  A stack of thin occluders at alternating depths makes nearly every pixel of a 32 x 8 region a
+    silhouette pixel, far more pairs than the list holds."""
+    H, W = 64, 96
+    rng = np.random.default_rng(5)
+    verts, faces = [], []
+    for i in range(0, W, 3):            # vertical slivers, 3 pixels wide, alternating near / far, slightly slanted
+        z, w = (0.2, 1.0) if (i // 3) % 2 else (-0.3, 2.0)
+        xa, xb = 2.0 * i / W - 1.0, 2.0 * (i + 3) / W - 1.0
+        base = len(verts)
+        verts += [(xa * w, -1.1 * w, z * w, w), (xb * w, -1.1 * w, z * w, w), (xb * w + 0.01, 1.1 * w, z * w, w), (xa * w + 0.01, 1.1 * w, z * w, w)]
+        faces += [(base, base + 1, base + 2), (base, base + 2, base + 3)]
+    s = {'vertices': np.asarray(verts, np.float32)[None], 'faces': np.asarray(faces, np.int32)[None]}
+    V = s['vertices'].shape[1]
+    s['vertex_colors'] = rng.uniform(0, 1, (1, V, C)).astype(np.float32)
+    s['background'] = rng.uniform(0, 1, (1, H, W, C)).astype(np.float32)
+    s['grad_pixels'] = rng.standard_normal((1, H, W, C)).astype(np.float32)
     want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
-    for tiles in (0x200, 0x400):
-        ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'])
-        gb, gv, gvc, _ = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
-                                                _t(s['grad_pixels'], gpu), H, W, C, flags=tiles)
+    for flags in (0, 1):
+        ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'], flags=flags, want_debug=True)
+        assert float((ow['debug_thingy'][..., 0] > 0).mean()) > 0.3   # the scene does what it is meant to
+        gb, gv, gvc, dbg = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
+                                                  _t(s['grad_pixels'], gpu), H, W, C, flags=flags, want_debug=True)
         assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
+        assert np.array_equal(dbg.cpu().numpy(), ow['debug_thingy'])
         _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
         _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
 
 
-@pytest.mark.parametrize('slots', ['32', '64'])
-@pytest.mark.parametrize('C', [1, 3, 4])
-def test_gradient_slot_table_sizes(gpu, oracle, monkeypatch, slots, C):
-    """The channel-specialised 32x16 gradient kernels come with a 64-slot and a 32-slot face table (the latter leaves
-    LDS for a third workgroup per CU); pinned here, on a mesh whose tiles see a few faces and on one whose tiles
-    overflow 32 slots (those faces take the direct-atomic path)."""
-    monkeypatch.setenv('DIRT_GRAD_SLOTS', slots)
-    for F, r_lo, r_hi in ((150, 0.1, 0.5), (2500, 0.01, 0.06)):
-        H, W = 96, 128
-        s = _batched(scenes.rand_scene(F, H, W, C, 71, r_lo, r_hi))
-        want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
-        ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'])
-        gb, gv, gvc, _ = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
-                                                _t(s['grad_pixels'], gpu), H, W, C, flags=0x200)
-        assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
-        _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
-        _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
+@pytest.mark.parametrize('W', [32, 33, 34, 35, 61, 64, 65, 67])
+@pytest.mark.parametrize('C', [1, 4, 5])
+def test_right_border_alias_taps(gpu, oracle, W, C):
+    """Quirk Q1 at the right image border: the aliased "channels" 1, 2 of a 1-channel group are the next two elements
+    of the flattened slice, which for the last interior columns lie in the NEXT image row (and past the end of the
+    tensor for the last rows of the last scene).  Frame widths around the tile width put those columns at every
+    position of a strip and of a tile; batch of 2 so that "the next scene" is also exercised."""
+    H = 37
+    s = scenes.batch_scene(80, H, W, C, seeds=[81, 82], r_lo=0.05, r_hi=0.4)
+    want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
+    ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'], want_debug=True)
+    gb, gv, gvc, dbg = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
+                                              _t(s['grad_pixels'], gpu), H, W, C, want_debug=True)
+    assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
+    assert np.array_equal(dbg.cpu().numpy(), ow['debug_thingy'])
+    _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
+    _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
+
+
+def test_duplicate_index_triples(gpu, oracle):
+    """Distinct faces over the SAME three vertex indices count as one face for the dilation test
+    (csrc/rasterise_grad_egl.cu:86-89 compares the index triples, not the primitives)."""
+    H, W, C = 48, 64, 3
+    s = scenes.rand_scene(60, H, W, C, 91, 0.1, 0.5, shared=True)
+    faces = np.concatenate([s['faces'], s['faces'][:20], s['faces'][5:15][:, [1, 2, 0]]], 0)  # exact repeats + rotated repeats
+    s = _batched(dict(s, faces=faces))
+    want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
+    got = _fwd_gpu(s, gpu)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'], want_debug=True)
+    gb, gv, gvc, dbg = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
+                                              _t(s['grad_pixels'], gpu), H, W, C, want_debug=True)
+    assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
+    assert np.array_equal(dbg.cpu().numpy(), ow['debug_thingy'])
+    _assert_grad_close(gvc.cpu().numpy(), ow['grad_vertex_colors'], 'grad_vertex_colors')
+    _assert_grad_close(gv.cpu().numpy(), ow['grad_vertices'], 'grad_vertices')
+
+
+def test_retain_graph_double_backward_is_pure(gpu, oracle):
+    """Two backward passes over one forward (retain_graph=True) each return the RasteriseGrad outputs of their own
+    grad_pixels: the reference's grad op is pure (csrc/rasterise_grad_egl.cu:244-250 clears its outputs)."""
+    s = scenes.rand_scene(150, 64, 80, 3, 33, 0.05, 0.3)
+    bg = _t(s['background'], gpu).requires_grad_(True)
+    v = _t(s['vertices'], gpu).requires_grad_(True)
+    vc = _t(s['vertex_colors'], gpu).requires_grad_(True)
+    px = ops.rasterise(bg, v, vc, _t(s['faces'], gpu))
+    g1 = _t(s['grad_pixels'], gpu)
+    g2 = torch.flip(g1, dims=(0,)) * 0.5
+    a = torch.autograd.grad(px, [bg, v, vc], g1, retain_graph=True)
+    a_copy = [t.clone() for t in a]
+    b = torch.autograd.grad(px, [bg, v, vc], g2, retain_graph=True)
+    c = torch.autograd.grad(px, [bg, v, vc], g1)
+    for t, t0 in zip(a, a_copy):
+        assert torch.equal(t, t0), 'a later backward changed gradients already returned'
+    pxn = px.detach().cpu().numpy()[None]
+    for got, g in ((a, g1), (b, g2), (c, g1)):
+        ow = oracle.backward(s['vertices'][None], s['faces'][None], pxn, g.cpu().numpy()[None])
+        assert np.array_equal(got[0].cpu().numpy(), ow['grad_background'][0])
+        _assert_grad_close(got[1].cpu().numpy(), ow['grad_vertices'][0], 'gv')
+        _assert_grad_close(got[2].cpu().numpy(), ow['grad_vertex_colors'][0], 'gvc')
+
+
+def test_misaligned_views_are_accepted(gpu, oracle):
+    """Slices such as x[1:] of a 5x5x3 batch start at addresses that are not multiples of 16; the reference accepts any
+    tensor, the C ABI wants 16-byte alignment: the wrapper copies."""
+    s = scenes.batch_scene(7, 5, 5, 3, seeds=[1, 2, 3], r_lo=0.2, r_hi=0.9)
+    t = {k: _t(s[k], gpu) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
+    bg, v, vc = (t[k][1:].detach().requires_grad_(True) for k in ('background', 'vertices', 'vertex_colors'))
+    assert bg.data_ptr() % 16 != 0
+    px = ops.rasterise_batch(bg, v, vc, t['faces'][1:])
+    px.backward(t['grad_pixels'][1:])
+    want = oracle.forward(s['background'][1:], s['vertices'][1:], s['vertex_colors'][1:], s['faces'][1:])
+    assert np.array_equal(px.detach().cpu().numpy().view(np.uint32), want.view(np.uint32))
+    ow = oracle.backward(s['vertices'][1:], s['faces'][1:], want, s['grad_pixels'][1:])
+    assert np.array_equal(bg.grad.cpu().numpy(), ow['grad_background'])
+    _assert_grad_close(v.grad.cpu().numpy(), ow['grad_vertices'], 'gv')
+    _assert_grad_close(vc.grad.cpu().numpy(), ow['grad_vertex_colors'], 'gvc')
