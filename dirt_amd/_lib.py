@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdirt_hip.so')
+LIB_PATH = os.environ.get('DIRT_AMD_LIBRARY') or os.path.join(_HERE, 'libdirt_hip.so')  # override: instrumented builds (tools/)
 ABI_VERSION = 1
 
 FLAG_Q1_INTENDED = 1

@@ -81,11 +81,11 @@ void drain_profile()
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
-    size_t recs_off, boxes_off, cells_off, entries_off, state_off, gv_off, gvc_off, total;
+    size_t recs_off, boxes_off, cells_off, entries_off, state_a_off, state_b_off, gv_off, gvc_off, total;
 };
 
 // Layout: [FaceRec x B*F | FaceBox x B*F | chunk x bin directory | per-chunk BinEntry segments (5 per face) |
-//          float4 per-pixel state {b0, b1, clip_w, face} x B*H*W | float grad_vertices x B*V*4 |
+//          float2 per-pixel state {clip_w, face} x B*H*W | float2 {b0, b1} x B*H*W | float grad_vertices x B*V*4 |
 //          float grad_vertex_colors x B*V*C]
 Workspace carve(int B, int V, int F, int H, int W, int C)
 {
@@ -97,7 +97,8 @@ Workspace carve(int B, int V, int F, int H, int W, int C)
     dirt::chunking(F, nchunk, chunk_faces);
     w.cells_off = off;   off = align_up(off + (size_t)B * nchunk * (dirt::MAX_BINS + 1) * sizeof(dirt::BinCell), 256);
     w.entries_off = off; off = align_up(off + (size_t)B * nchunk * 5 * (size_t)chunk_faces * sizeof(dirt::BinEntry), 256);
-    w.state_off = off;   off = align_up(off + (size_t)B * H * W * sizeof(float4), 256);
+    w.state_a_off = off; off = align_up(off + (size_t)B * H * W * sizeof(float2), 256);
+    w.state_b_off = off; off = align_up(off + (size_t)B * H * W * sizeof(float2), 256);
     // gradient accumulators of the backward pass, pre-cleared by a KEEP_STATE forward (dirt_state_grad_buffers)
     w.gv_off = off;      off = align_up(off + (size_t)B * V * 4 * sizeof(float), 256);
     w.gvc_off = off;     off = align_up(off + (size_t)B * V * C * sizeof(float), 256);
@@ -110,7 +111,8 @@ struct Carved {
     dirt::FaceBox* boxes;
     dirt::BinCell* cells;
     dirt::BinEntry* entries;
-    float4* state;
+    float2* state_a;
+    float2* state_b;
     float* gv;
     float* gvc;
 };
@@ -167,7 +169,8 @@ Carved carved(void* workspace, const Workspace& w)
     c.boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
     c.cells = reinterpret_cast<dirt::BinCell*>(ws + w.cells_off);
     c.entries = reinterpret_cast<dirt::BinEntry*>(ws + w.entries_off);
-    c.state = reinterpret_cast<float4*>(ws + w.state_off);
+    c.state_a = reinterpret_cast<float2*>(ws + w.state_a_off);
+    c.state_b = reinterpret_cast<float2*>(ws + w.state_b_off);
     c.gv = reinterpret_cast<float*>(ws + w.gv_off);
     c.gvc = reinterpret_cast<float*>(ws + w.gvc_off);
     return c;
@@ -192,7 +195,7 @@ dirt::RasterParams raster_params(const Carved& c, const dirt::GeomParams& g, int
     dirt::RasterParams p;
     p.flags = flags;
     p.recs = c.recs; p.cells = c.cells; p.entries = c.entries; p.nchunk = g.nchunk; p.chunk_faces = g.chunk_faces;
-    p.background = nullptr; p.vertex_colors = nullptr; p.pixels = nullptr; p.vis = nullptr; p.state = nullptr;
+    p.background = nullptr; p.vertex_colors = nullptr; p.pixels = nullptr; p.vis = nullptr; p.state_a = nullptr; p.state_b = nullptr;
     p.V = g.V; p.F = g.F; p.H = g.H; p.W = g.W; p.C = C;
     p.grid = g.grid; p.tiles_x = 0; p.tiles_y = 0;
     return p;
@@ -242,7 +245,7 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
     }
     dirt::RasterParams p = raster_params(c, g, C, flags);
     p.background = background; p.vertex_colors = vertex_colors; p.pixels = pixels;
-    if (flags & DIRT_FLAG_KEEP_STATE) p.state = c.state;
+    if (flags & DIRT_FLAG_KEEP_STATE) { p.state_a = c.state_a; p.state_b = c.state_b; }
     {
         Scope sc(prof, SLOT_RASTER_FWD, stream);
         HIP_TRY(who, dirt::launch_raster(p, B, false, stream));
@@ -327,14 +330,14 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
             HIP_TRY(who, dirt::launch_geometry(g, stream));
         }
         dirt::RasterParams rp = raster_params(c, g, C, flags);
-        rp.state = c.state;
+        rp.state_a = c.state_a; rp.state_b = c.state_b;
         {
             Scope sc(prof, SLOT_RASTER_VIS, stream);
             HIP_TRY(who, dirt::launch_raster(rp, B, true, stream));
         }
     }
     dirt::GradParams gp;
-    gp.state = c.state; gp.faces = faces; gp.shared_faces = (flags & DIRT_FLAG_SHARED_FACES) ? 1 : 0;
+    gp.state_a = c.state_a; gp.state_b = c.state_b; gp.faces = faces; gp.shared_faces = (flags & DIRT_FLAG_SHARED_FACES) ? 1 : 0;
     gp.pixels = pixels; gp.grad_pixels = grad_pixels;
     gp.grad_background = grad_background; gp.grad_vertices = grad_vertices;
     gp.grad_vertex_colors = grad_vertex_colors; gp.debug_thingy = debug_thingy;

@@ -4,26 +4,27 @@
 // evaluating every channel group of dirt/rasterise_ops.py:145-165 inside one launch, the N
 // per-group RasteriseGrad ops (and N GL re-draws) the reference issues for C not in {1,3}.
 //
-// Input: the per-pixel state the raster kernel leaves behind -- one float4 {b0, b1, clip_w, face} per
-// pixel, the counterpart of the reference's two RGBA32F surfaces (csrc/rasterise_grad_egl.cpp:432-456),
-// produced by the forward pass itself when it keeps its state -- plus `faces` for the vertex indices.
+// Input: the per-pixel state the raster kernel leaves behind -- two float2 planes, {clip_w, face} and {b0, b1}, the
+// counterpart of the reference's two RGBA32F surfaces (csrc/rasterise_grad_egl.cpp:432-456), produced by the forward
+// pass itself when it keeps its state -- plus `faces` for the vertex indices.
 //
 // The reference issues up to 3C+9 global float atomics per covered pixel (:140,228-230) and reads its 3x3
 // neighbourhood with 27 scalar loads.  Here:
-//   * a 256-thread workgroup stages one 32 x 32 tile (+ halo) in LDS -- the pass's channels of `pixels` as
-//     planes, and {clip_w, i0, i1, i2} of every pixel (vertex indices gathered from `faces`) -- then its four
-//     waves work independently, with no further barrier: a wave owns 32 x 8 pixels, a lane a 4 x 1 strip, so
-//     that Scharr taps, address arithmetic and predicates are shared by four pixels;
-//   * nothing is accumulated in memory.  A lane keeps, per pixel, the barycentrics and seven factors
-//     (four colour channels, and the x / y / w position factors of the channel groups that were not dilated);
-//     the rare dilated (pixel, group) pairs -- which take a NEIGHBOUR's barycentrics and face -- go to a short
-//     per-wave list in LDS;
-//   * the wave then walks the distinct faces it has seen: for each, every lane forms its masked partial sums
-//     (3 vertices x 7 values), the 21 sums are reduced across the wave with a transposing butterfly
-//     (v_permlane32_swap / v_permlane16_swap / DPP row operations: 21 totals land in 21 different lanes at
-//     ~60 instructions), and ONE global_atomic_add_f32 instruction adds them to the face's three vertices.
-//     Per wave and face that is one atomic instruction instead of 21 x 256; no LDS atomics, no hash table,
-//     no fixed point.
+//   * a 256-thread workgroup stages one 32 x 32 tile (+ halo) in LDS -- the pass's channels of `pixels` as planes and
+//     {clip_w, face} of every pixel -- then its four waves work independently, with no further barrier: a wave owns
+//     32 x 8 pixels, a lane a 4 x 1 strip, so that Scharr taps, neighbour tests and address arithmetic are shared by four
+//     pixels;
+//   * the face index stands for the reference's index triple (:86-89): two faces with the same ordered triple have the
+//     same set-up record, hence the same coverage and depth at every sample, and the lower index wins every tie -- at
+//     most one of them is ever visible, so among visible faces index and triple correspond one to one;
+//   * every position gradient is b_k(t) * (fx, fy, fw(t)) for some TARGET pixel t -- the pixel itself, or the neighbour
+//     it was dilated from -- with fw linear in (fx, fy).  The (fx, fy) are summed per target first: own pixels in
+//     registers, neighbours through a per-wave inbox in LDS (ds_add_f32 from the few dilated lanes), whose one-pixel
+//     ring collects what belongs to pixels of other waves; then fw is formed once per pixel;
+//   * nothing else is accumulated in memory.  The wave walks the distinct faces it has seen: for each, every lane forms
+//     its masked partial sums (3 vertices x {x, y, w, colours}), the <= 21 sums are reduced across the wave with a
+//     transposing butterfly (~80 instructions: 21 totals land in 21 different lanes), and ONE global_atomic_add_f32
+//     instruction adds them to the face's three vertices.  No LDS accumulators, no hash table, no fixed point.
 // Variable names in the per-pixel arithmetic follow the CUDA source.
 #include "dirt_device.h"
 #include "dirt_launch.h"
@@ -32,68 +33,92 @@
 
 namespace dirt {
 
+#ifdef DIRT_TRACE
+// Per-wave phase timestamps (s_memtime) for tools/trace_grad.py; compiled only into the tracing build of the library.
+__device__ long long* g_trace_grad = nullptr;
+extern "C" void dirt_debug_set_trace_grad(void* p)
+{
+    long long* q = reinterpret_cast<long long*>(p);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_grad), &q, sizeof(q));
+}
+#define GMARK() do { if (tr_n < 12) { long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tr_t[tr_n++] = t_; } } while (0)
+#define GCOUNT(i, v) do { tr_c[i] += (v); } while (0)
+#else
+#define GMARK() do {} while (0)
+#define GCOUNT(i, v) do {} while (0)
+#endif
+
 constexpr int GT = 32;                  // tile side (pixels)
 constexpr int GTHREADS = 256;           // 4 waves: wave w owns rows 8w .. 8w+7, lane l the strip x = 4 * (l & 7) .. +3 of row l >> 3
 constexpr int PR = GT + 2;              // staged rows: y0-1 .. y0+32
 constexpr int PS = 36;                  // plane row stride (floats): column (x - x0) for x0 .. x0+34, column 35 holds x0-1
-constexpr int VS = GT + 2;              // state tile row stride (float4)
+constexpr int VS = 36;                  // state tile row stride (float2): column (x - x0) + 2, so that strips are 16-byte aligned
 constexpr int PC = 4;                   // channels per pass: whole channel groups that fit in 4 channels
-constexpr int LIST_CAP = 64;            // dilated (pixel, group) pairs listed per wave; the rest use direct atomics
-constexpr int ENTRY_FLOATS = 8;         // {i0, i1, i2, target pixel | fx, fy, fw, -}
-constexpr int ENTRIES_PER_PLANE = 6 * PS / ENTRY_FLOATS;  // a wave's private rows of one plane: 6 x 36 floats = 27 entries
+constexpr int IS = 36;                  // inbox row stride (float2 cells): cell (ty + 1) * 36 + tx + 2 for ty in -1..8, tx in -1..32
+constexpr int ICELLS = 10 * IS;         // ... of a wave's 32 x 8 region and the one-pixel ring around it
+constexpr int RING = 2 * 34 + 2 * 8;    // ring cells: what the wave's pixels sent to pixels of other waves
+
+// Reduce N (16 or 24) per-lane values across the 64 lanes of the wave: a transposing butterfly.  Inside a DPP row of 16
+// lanes, every level pairs lane l with its mirror image (row_mirror, row_half_mirror, the two quad permutations) and
+// pairs value i with value i + (half of what is left): a lane keeps one of the two values, sends the other to its partner
+// and adds what it receives -- two selects and one DPP add per pair, and half as many registers after each level.  After
+// four levels one or two registers hold, per row, 16 different values in 16 lanes; v_permlane32_swap and
+// v_permlane16_swap then add the four rows.  ~70 instructions for 24 values (six plain DPP reductions per value would
+// be 144).  Returns the totals in these lanes (c = lane & 15, bits b3 b2 b1 b0):
+//   N = 16: lanes 0-15:  value  b0 + 2 b1 + 4 b2 + 8 b3
+//   N = 24: lanes 0-15:  value  b0 + 3 b1 + 6 b2 + 12 b3;   lanes 32-47 (b0 = 0): value 2 + 3 b1 + 6 b2 + 12 b3
+// (reduce_value_of_lane() below); other lanes hold copies or nothing of interest.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 
 template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v)
+__device__ __forceinline__ float pack_pair(float lo, float hi, bool upper)
 {
-    return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+    const float keep = upper ? hi : lo, send = upper ? lo : hi;
+    return keep + dpp_mov<CTRL>(send);
 }
 
-// Sum over the 16 lanes of a DPP row, left in all 16 of them.
-__device__ __forceinline__ float row_sum16(float v)
-{
-    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);   // row_half_mirror
-    return dpp_add<0x140>(v);  // row_mirror
-}
-
-// Reduce NV4 (a multiple of 4) per-lane values across the 64 lanes of the wave.  Returns, in lane 16 * r + c with
-// c < NV4 / 4, the total of value c + (NV4 / 4) * r; other lanes hold nothing of interest.
-//   step 1: v_permlane32_swap pairs value i with value i + NV4/2: one add leaves value i's half-sums in lanes 0-31
-//           and value (i + NV4/2)'s in lanes 32-63 -- half the registers;
-//   step 2: v_permlane16_swap does the same between DPP rows -- a quarter of the registers, each row a different value;
-//   step 3: four DPP adds inside the rows.
-template <int NV4>
+template <int N>
 __device__ __forceinline__ float wave_reduce_scatter(const float* val, int lane)
 {
-    static_assert(NV4 % 4 == 0, "NV4 must be a multiple of 4");
-    constexpr int H1 = NV4 / 2, H2 = NV4 / 4;
-    float r1[H1];
+    static_assert(N == 16 || N == 24, "16 or 24 values");
+    constexpr int ROW_MIRROR = 0x140, ROW_HALF_MIRROR = 0x141, QUAD_MIRROR = 0x1B /* [3,2,1,0] */, QUAD_SWAP = 0xB1 /* [1,0,3,2] */;
+    const bool u8 = (lane & 8) != 0, u4 = (lane & 4) != 0, u2 = (lane & 2) != 0, u1 = (lane & 1) != 0;
+    float a[N / 2], b[N / 4], c[N / 8];
 #pragma unroll
-    for (int i = 0; i < H1; ++i) {
-        const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(val[i]), __float_as_uint(val[i + H1]), false, false);
-        r1[i] = __uint_as_float(s[0]) + __uint_as_float(s[1]);
-    }
-    float r2[H2];
+    for (int i = 0; i < N / 2; ++i) a[i] = pack_pair<ROW_MIRROR>(val[i], val[i + N / 2], u8);
 #pragma unroll
-    for (int i = 0; i < H2; ++i) {
-        const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(r1[i]), __float_as_uint(r1[i + H2]), false, false);
-        r2[i] = __uint_as_float(s[0]) + __uint_as_float(s[1]);
-    }
-    const int c = lane & 15;
-    float out = row_sum16(r2[0]);
+    for (int i = 0; i < N / 4; ++i) b[i] = pack_pair<ROW_HALF_MIRROR>(a[i], a[i + N / 4], u4);
 #pragma unroll
-    for (int i = 1; i < H2; ++i) {
-        const float t = row_sum16(r2[i]);
-        out = (c == i) ? t : out;
-    }
-    return out;
+    for (int i = 0; i < N / 8; ++i) c[i] = pack_pair<QUAD_MIRROR>(b[i], b[i + N / 8], u2);
+    float r0 = pack_pair<QUAD_SWAP>(c[0], c[1], u1);  // 16 values per row
+    float r1 = r0;
+    if (N == 24) r1 = c[2] + dpp_mov<QUAD_SWAP>(c[2]);  // 8 values per row, each in two lanes
+    // the four rows: halves, then rows of a half
+    auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r1), false, false);
+    const float t = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);   // lanes 0-31: r0 (rows 0+2 | 1+3), lanes 32-63: r1
+    auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    return __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+}
+
+// The value whose total wave_reduce_scatter<N> leaves in `lane`, or -1.
+template <int N>
+__device__ __forceinline__ int reduce_value_of_lane(int lane)
+{
+    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, row = lane >> 4;
+    if (N == 16) return row == 0 ? b0 + 2 * b1 + 4 * b2 + 8 * b3 : -1;
+    if (row == 0) return b0 + 3 * b1 + 6 * b2 + 12 * b3;
+    if (row == 2 && b0 == 0) return 2 + 3 * b1 + 6 * b2 + 12 * b3;
+    return -1;
 }
 
 // Scharr responses of one channel from global memory for an aliased (quirk Q1) channel whose taps run past the
 // end of the image row: the tap centre is pixel (row y, column x) of scene iib, `shift` elements further on in the
 // flattened [B,H,W] slice; reads past the end of the tensor are clamped to its last element (undefined in the
-// reference).  Rare (only the last columns of a frame): behind wave-uniform branches, no function call in the kernel.
+// reference).  Rare (only the last columns of a frame): used by alias_wrap_fixup only.
 __device__ __forceinline__ float2 scharr_taps_wrapped(const float* __restrict__ pixels, int B, int H, int W, int C, int iib, int y,
                                                   int x, int shift, int c)
 {
@@ -114,6 +139,24 @@ __device__ __forceinline__ float2 scharr_taps_wrapped(const float* __restrict__ 
     m1 = d1 * (3.f / 32.f); m2 = d2 * (10.f / 32.f);
     sy = m1 + m2;
     return make_float2(sx, sy);
+}
+
+// Quirk Q1 at the right image border: for the pixels of a strip (first column xs, row y) flagged in `which`, the
+// aliased "channels" 1, 2 of 1-channel group c lie in the next image row; their dilation axis (:185) is decided again
+// from global memory and replaces bits shift .. shift+3 of `bits`.  Rare: a rolled loop behind a wave-uniform branch.
+__device__ __forceinline__ uint32_t alias_wrap_fixup(const float* __restrict__ pixels, int B, int H, int W, int C, int iib, int y,
+                                                  int xs, int c, uint32_t which, uint32_t bits, int shift)
+{
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        if (!((which >> j) & 1u)) continue;
+        const float2 s0 = scharr_taps_wrapped(pixels, B, H, W, C, iib, y, xs + j, 0, c);
+        const float2 s1 = scharr_taps_wrapped(pixels, B, H, W, C, iib, y, xs + j, 1, c);
+        const float2 s2 = scharr_taps_wrapped(pixels, B, H, W, C, iib, y, xs + j, 2, c);
+        const float l1x = (fabsf(s0.x) + fabsf(s1.x)) + fabsf(s2.x), l1y = (fabsf(s0.y) + fabsf(s1.y)) + fabsf(s2.y);
+        bits = (bits & ~(1u << (shift + j))) | ((l1x > l1y) ? (1u << (shift + j)) : 0u);
+    }
+    return bits;
 }
 
 // The reference's diagnostic output (csrc/rasterise_grad_egl.cu:150-151,172) of one pixel, for the first channel group
@@ -155,8 +198,13 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
 {
     constexpr int NPLANES = CSPEC ? CSPEC : PC;
     __shared__ __align__(16) float s_pix[NPLANES][PR][PS];  // the pass's channels of `pixels`, edge clamped
-    __shared__ float4 s_vw[PR][VS];                         // {clip_w, i0, i1, i2} of every pixel of the halo'd tile
+    __shared__ __align__(16) float2 s_vw[PR][VS];           // {clip_w, face} of every pixel of the halo'd tile
+    __shared__ __align__(16) float2 s_inbox[GTHREADS / 64][ICELLS];  // per wave: (fx, fy) sent to each pixel of its region + ring
 
+#ifdef DIRT_TRACE
+    long long tr_t[12]; int tr_n = 0; long long tr_c[4] = {0, 0, 0, 0};
+#endif
+    GMARK();  // 0 start
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -171,7 +219,8 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
     // non-negative 32-bit byte offset: (row - row0) * W + column, times the element size.
     const int row0 = max(y0 - 1, 0);
     const size_t origin = (size_t)iib * frame + (size_t)row0 * W;   // pixel index of (row0, column 0)
-    const float4* __restrict__ state_t = p.state + origin;
+    const float2* __restrict__ state_a = p.state_a + origin;         // {clip_w, face}
+    const float2* __restrict__ state_b = p.state_b + origin;         // {b0, b1}
     const float* __restrict__ pixels_t = p.pixels + origin * C;
     const float* __restrict__ gpix_t = p.grad_pixels + origin * C;
     float* __restrict__ gbk_t = p.grad_background + origin * C;
@@ -188,7 +237,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
     const int xs = x0 + 4 * sx;                 // first pixel of the strip
     const int y = y0 + 8 * wave + ry;           // tensor row (top row first)
     const int hr = 8 * wave + ry + 1;           // its row in the halo'd tile
-    // pixel index, relative to (row0, 0), of the strip's first pixel; lanes outside the frame address its last pixel
+    // pixel index, relative to (row0, 0), of the strip's first pixel (lanes outside the frame: a valid one)
     const uint32_t own_rel = (uint32_t)((min(y, H - 1) - row0) * W + min(xs, W - 1));
     bool in_px[4], interior[4];
 #pragma unroll
@@ -196,6 +245,8 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
         in_px[j] = (xs + j < W) & (y < H);
         interior[j] = in_px[j] & (xs + j > 0) & (y > 0) & (xs + j < W - 1) & (y < H - 1);
     }
+    float2* const inbox = &s_inbox[wave][0];
+    const int my_cell = (ry + 1) * IS + 4 * sx + 2;   // the strip's first pixel in the inbox
 
     // channels of a pass: whole channel groups (dirt/rasterise_ops.py:148-152) starting at c0 that fit in PC channels
     auto pass_channels = [&](int c0) {
@@ -240,39 +291,45 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
                 if (ch < nch) s_pix[ch][row][col] = v[k][ch];
         }
     };
+    auto zero_inbox = [&]() {  // 360 cells: six per lane of the first sixty
+        if (lane < ICELLS / 6) {
+            float4* z = reinterpret_cast<float4*>(inbox + 6 * lane);
+            z[0] = make_float4(0.f, 0.f, 0.f, 0.f); z[1] = make_float4(0.f, 0.f, 0.f, 0.f); z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
 
-    // ---- phase A: the visibility "surfaces" of the tile + 1-pixel halo -- what the backward fragment shader writes
-    //      (csrc/shaders.cpp:64-77) over the clear values of csrc/rasterise_grad_egl.cpp:442-445 -- as {clip_w,
-    //      i0, i1, i2}.  Halo positions outside the frame are clamped; they are only ever consulted for interior
-    //      pixels, whose neighbours are inside the frame. ----
+    // ---- phase A: the visibility "surface" of the tile + 1-pixel halo -- what the backward fragment shader writes
+    //      (csrc/shaders.cpp:64-77) over the clear values of csrc/rasterise_grad_egl.cpp:442-445 -- as {clip_w, face}.
+    //      Halo positions outside the frame are clamped; they are only ever consulted for interior pixels, whose
+    //      neighbours are inside the frame. ----
     float stage_v[PITEMS][PC];
     stage_load(0, pass_channels(0), stage_v);
     {
-        constexpr int VITEMS = (PR * VS + GTHREADS - 1) / GTHREADS;
-        float4 rec[VITEMS];
+        constexpr int VITEMS = (PR * PR + GTHREADS - 1) / GTHREADS;
+        float2 rec[VITEMS];
 #pragma unroll
         for (int k = 0; k < VITEMS; ++k) {
-            const int i = min(tid + k * GTHREADS, PR * VS - 1);
-            const int row = i / VS, ci = i - row * VS;
+            const int i = min(tid + k * GTHREADS, PR * PR - 1);
+            const int row = i / PR, ci = i - row * PR;
             const int cy = min(max(y0 - 1 + row, 0), H - 1), cx = min(max(x0 - 1 + ci, 0), W - 1);
-            rec[k] = ld_off<float4>(state_t, (uint32_t)((cy - row0) * W + cx) * 16u);
-        }
-        int vid[VITEMS][3];
-#pragma unroll
-        for (int k = 0; k < VITEMS; ++k) {
-            const int f = __float_as_int(rec[k].w);
-            const uint32_t fo = (uint32_t)max(f, 0) * 12u;
-            vid[k][0] = ld_off<int>(faces, fo); vid[k][1] = ld_off<int>(faces, fo + 4u); vid[k][2] = ld_off<int>(faces, fo + 8u);
-            if (f < 0) { vid[k][0] = -1; vid[k][1] = -1; vid[k][2] = -1; }
+            rec[k] = ld_off<float2>(state_a, (uint32_t)((cy - row0) * W + cx) * 8u);
         }
 #pragma unroll
         for (int k = 0; k < VITEMS; ++k) {
             const int i = tid + k * GTHREADS;
-            if (i >= PR * VS) continue;
-            const int row = i / VS, ci = i - row * VS;
-            s_vw[row][ci] = make_float4(rec[k].z, __int_as_float(vid[k][0]), __int_as_float(vid[k][1]), __int_as_float(vid[k][2]));
+            if (i >= PR * PR) continue;
+            const int row = i / PR, ci = i - row * PR;
+            s_vw[row][ci + 1] = rec[k];
         }
     }
+    // own barycentrics b0, b1
+    float bk[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float2 q = ld_off<float2>(state_b, in_px[j] ? (own_rel + (uint32_t)j) * 8u : 0u);
+        bk[j][0] = q.x; bk[j][1] = q.y; bk[j][2] = (1.f - q.x) - q.y;
+    }
+    zero_inbox();
 
     // One pass = the channel groups that fit in PC channels, starting at channel c0.  A pass has one of four
     // shapes -- {3}, {3,1}, {1}, {1,1} (dirt/rasterise_ops.py:148-152 packs groups of 3 while >= 3 channels remain,
@@ -283,8 +340,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
         constexpr int G0 = decltype(g0_tag)::value;
         constexpr int NG = 1 + (NCH - G0);          // channel groups in the pass
         constexpr int NV = 9 + 3 * NCH;             // values per face: 3 vertices x {x, y, w} + 3 vertices x NCH colours
-        constexpr int NV4 = (NV + 3) / 4 * 4;
-        constexpr int LCAP = (NPLANES * ENTRIES_PER_PLANE < LIST_CAP) ? NPLANES * ENTRIES_PER_PLANE : LIST_CAP;  // planes beyond NCH are idle
+        constexpr int NR = NV <= 16 ? 16 : 24;      // ... padded to what the wave reduction takes
 
         if (c0 != 0) stage_load(c0, NCH, stage_v);
         // this strip's grad_pixels
@@ -306,8 +362,11 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
                 for (int ch = 0; ch < NCH; ++ch) g[j][ch] = ld_off<float>(gpix_t, off + 4u * ch);
             }
         }
+        GMARK();  // 1 loads issued, state tile stored
         stage_store(NCH, stage_v);
+        GMARK();  // 2 planes stored
         __syncthreads();
+        GMARK();  // 3 barrier passed
 
         // ---- Scharr (:126-127, operation for operation: negative-offset minus positive-offset, offset_y is up = the
         //      previous tensor row), streamed per channel into what is needed of it: the direction choice of :185 from the
@@ -373,53 +432,52 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
                         // quirk Q1: "channels" 1,2 of a 1-channel group = elements (pixel + 1, + 2) of the flattened
                         // [B,H,W,1] slice.  Only the L1 norms of interior pixels use them, and for an interior pixel the
                         // taps are unclamped: column + ch, which is staged unless it runs past the end of the image row
-                        // (then it wraps to the next row: read from global memory).
-                        float ax1 = Sx[j + 1], ay1 = Sy[j + 1], ax2 = Sx[j + 2], ay2 = Sy[j + 2];
-                        if (!q1_intended && x0 + GT + 3 > W) {  // only tiles on the right image border
-                            const bool wraps1 = interior[j] && xs + j + 2 > W - 1, wraps2 = interior[j] && xs + j + 3 > W - 1;
-                            if (__builtin_amdgcn_ballot_w64(wraps2) != 0ull) {
-                                if (wraps1) {
-                                    const float2 w2 = scharr_taps_wrapped(p.pixels, p.B, H, W, C, iib, y, xs + j, 1, c0 + ch);
-                                    ax1 = w2.x; ay1 = w2.y;
-                                }
-                                if (wraps2) {
-                                    const float2 w2 = scharr_taps_wrapped(p.pixels, p.B, H, W, C, iib, y, xs + j, 2, c0 + ch);
-                                    ax2 = w2.x; ay2 = w2.y;
-                                }
-                            }
-                        }
+                        // (the last two interior columns of the frame are corrected below: alias_wrap_fixup)
                         const float a0x = fabsf(Sx[j]), a0y = fabsf(Sy[j]);
-                        l1x[j] = q1_intended ? a0x : (a0x + fabsf(ax1)) + fabsf(ax2);
-                        l1y[j] = q1_intended ? a0y : (a0y + fabsf(ay1)) + fabsf(ay2);
+                        l1x[j] = q1_intended ? a0x : (a0x + fabsf(Sx[j + 1])) + fabsf(Sx[j + 2]);
+                        l1y[j] = q1_intended ? a0y : (a0y + fabsf(Sy[j + 1])) + fabsf(Sy[j + 2]);
                     }
                 }
                 if (last_of_group) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) horiz_bits |= (l1x[j] > l1y[j]) ? (1u << (4 * gi + j)) : 0u;  // :185
+                    if (single && !q1_intended && x0 + GT + 3 > W) {  // wave-uniform: only tiles on the right image border
+                        uint32_t ib = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ib |= (interior[j] && xs + j + 3 > W - 1) ? (1u << j) : 0u;
+                        if (__builtin_amdgcn_ballot_w64(ib != 0u) != 0ull)
+                            horiz_bits = alias_wrap_fixup(p.pixels, p.B, H, W, C, iib, y, xs, c0 + ch, ib, horiz_bits, 4 * gi);
+                    }
                     asm volatile("" : "+v"(horiz_bits));  // decided here: the norms' registers are free again
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one channel's taps at a time
             }
         }
+        GMARK();  // 4 Scharr done
 
-        // ---- own pixels: clip_w and vertex indices (the halo'd tile), barycentrics b0, b1 (the state record) ----
-        float w_own[4];
-        int key[4][3];
-        bool covered[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 q = s_vw[hr][4 * sx + j + 1];
-            w_own[j] = q.x;
-            covered[j] = in_px[j] & (__float_as_int(q.y) >= 0);
-            key[j][0] = covered[j] ? __float_as_int(q.y) : -1;
-            key[j][1] = covered[j] ? __float_as_int(q.z) : -1;
-            key[j][2] = covered[j] ? __float_as_int(q.w) : -1;
+        // ---- the strip and its eight neighbours: clip_w and face ----
+        float w_own[4], w_up[4], w_dn[4], w_l, w_r;
+        int f_own[4], f_up[4], f_dn[4], f_l, f_r;
+        {
+            const float2* rowp = &s_vw[hr][4 * sx + 2];
+            const float4 a = *reinterpret_cast<const float4*>(rowp), b = *reinterpret_cast<const float4*>(rowp + 2);
+            w_own[0] = a.x; f_own[0] = __float_as_int(a.y); w_own[1] = a.z; f_own[1] = __float_as_int(a.w);
+            w_own[2] = b.x; f_own[2] = __float_as_int(b.y); w_own[3] = b.z; f_own[3] = __float_as_int(b.w);
+            const float2 l = rowp[-1], r = rowp[4];
+            w_l = l.x; f_l = __float_as_int(l.y); w_r = r.x; f_r = __float_as_int(r.y);
+            const float4 c = *reinterpret_cast<const float4*>(rowp - VS), d = *reinterpret_cast<const float4*>(rowp - VS + 2);
+            w_up[0] = c.x; f_up[0] = __float_as_int(c.y); w_up[1] = c.z; f_up[1] = __float_as_int(c.w);
+            w_up[2] = d.x; f_up[2] = __float_as_int(d.y); w_up[3] = d.z; f_up[3] = __float_as_int(d.w);
+            const float4 e = *reinterpret_cast<const float4*>(rowp + VS), f = *reinterpret_cast<const float4*>(rowp + VS + 2);
+            w_dn[0] = e.x; f_dn[0] = __float_as_int(e.y); w_dn[1] = e.z; f_dn[1] = __float_as_int(e.w);
+            w_dn[2] = f.x; f_dn[2] = __float_as_int(f.y); w_dn[3] = f.z; f_dn[3] = __float_as_int(f.w);
         }
-        float bk[4][3];
+        bool covered[4];
+        int key[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float2 q = ld_off<float2>(state_t, in_px[j] ? (own_rel + (uint32_t)j) * 16u : 0u);
-            bk[j][0] = q.x; bk[j][1] = q.y;
+            covered[j] = in_px[j] & (f_own[j] >= 0);
+            key[j] = covered[j] ? f_own[j] : -1;
         }
 
         // ---- background gradient (:143-147): grad_pixels where nothing is covered, zero elsewhere ----
@@ -440,142 +498,139 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
             }
         }
 
-        // ---- per pixel factors: the colour gradients of vertex k are b_k * g[c] (:135-142); the position gradients
-        //      b_k * (fx, fy, fw) (:224-230) with the factors summed over the groups that were not dilated ----
+        // ---- dilation (:155-194).  A pixel takes the fragment of the neighbour n at +d, else at -d, when that neighbour
+        //      is covered, is another face (:86-89) and is closer (:165); d is +-x or +-y.  The four tests of a pixel do not
+        //      depend on the channel group, and the horizontal ones are shared by adjacent pixels of the strip. ----
+        bool ok_l[4], ok_r[4], ok_u[4], ok_d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float wl = j == 0 ? w_l : w_own[j - 1], wr = j == 3 ? w_r : w_own[j + 1];
+            const int fl = j == 0 ? f_l : f_own[j - 1], fr = j == 3 ? f_r : f_own[j + 1];
+            // the pixel's own face as the state tile has it (an uncovered pixel, -1, differs from any face)
+            ok_l[j] = interior[j] & (fl >= 0) & (fl != f_own[j]) & (w_own[j] > wl);
+            ok_r[j] = interior[j] & (fr >= 0) & (fr != f_own[j]) & (w_own[j] > wr);
+            ok_u[j] = interior[j] & (f_up[j] >= 0) & (f_up[j] != f_own[j]) & (w_own[j] > w_up[j]);
+            ok_d[j] = interior[j] & (f_dn[j] >= 0) & (f_dn[j] != f_own[j]) & (w_own[j] > w_dn[j]);
+        }
+
+        // ---- position factors (:196-232): the gradients of vertex k are b_k * (fx, fy, fw) with
+        //          fx = dL_dx * (W/2) / w,  fy = dL_dy * (H/2) / w,  fw = -(fx * ndc_x + fy * ndc_y)
+        //      (:210-222: clip_x = sum b_k * vertex_k.x is the fragment's own clip position = its NDC position times
+        //      clip_w -- perspective-correct barycentrics -- so no vertex gather is needed; one v_rcp_f32, 1 ulp; agrees to
+        //      float rounding), everything taken at the pixel whose fragment is used.  (fx, fy) are summed per such
+        //      TARGET pixel -- own pixels in registers, neighbours through the inbox -- and fw is formed once per pixel. ----
         float fpos[4][3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { fpos[j][0] = 0.f; fpos[j][1] = 0.f; fpos[j][2] = 0.f; }
-
-        // the wave's private rows of the planes hold the list of dilated (pixel, group) pairs: rows 8w+2 .. 8w+7 of the
-        // halo'd tile are read by this wave only, and its Scharr reads are complete
-        uint32_t nlist = 0;  // wave-uniform
-        auto entry_ptr = [&](uint32_t e) -> float* {
-            const uint32_t pl = e / ENTRIES_PER_PLANE, k = e - pl * ENTRIES_PER_PLANE;
-            return &s_pix[pl][8 * wave + 2][0] + k * ENTRY_FLOATS;
-        };
-
-        // ---- dilation (:155-194) and position factors (:196-232) of every (pixel, group) ----
+        for (int j = 0; j < 4; ++j) { fpos[j][0] = 0.f; fpos[j][1] = 0.f; }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            const int c_begin = c0 + (gi == 0 ? 0 : G0 + gi - 1);
-            const int G = gi == 0 ? G0 : 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int xj = xs + j;
                 // direction: x if L1(Sx) > L1(Sy) else y (:185), negated on odd (x + y) (:186-190).  The reference's
                 // offsets are in GL buffer orientation (y up): tensor row = y - offset_y.
-                const int sgn = ((xj + y) & 1) ? -1 : 1;
                 const bool horiz = (horiz_bits >> (4 * gi + j)) & 1u;
-                const int dx = horiz ? sgn : 0, dy = horiz ? 0 : -sgn;
-                const int e0 = hr * VS + 4 * sx + j + 1;
-                const int d = dy * VS + dx;
-                const float4 n1 = (&s_vw[0][0])[e0 + d], n2 = (&s_vw[0][0])[e0 - d];
-                // index triples differ (:86-89): an uncovered pixel (-1,-1,-1) differs from any face
-                const bool c1 = __float_as_int(n1.y) >= 0, c2 = __float_as_int(n2.y) >= 0;
-                const bool t1 = ((__float_as_int(n1.y) ^ key[j][0]) | (__float_as_int(n1.z) ^ key[j][1]) | (__float_as_int(n1.w) ^ key[j][2])) != 0;
-                const bool t2 = ((__float_as_int(n2.y) ^ key[j][0]) | (__float_as_int(n2.z) ^ key[j][1]) | (__float_as_int(n2.w) ^ key[j][2])) != 0;
-                const bool ok1 = interior[j] & c1 & t1 & (w_own[j] > n1.x);          // :165, first attempt (:191)
-                const bool ok2 = interior[j] & !ok1 & c2 & t2 & (w_own[j] > n2.x);   // opposite direction if the first failed (:192-193)
-                const bool dilated = ok1 | ok2;
-                const int ddx = ok1 ? dx : (ok2 ? -dx : 0), ddy = ok1 ? dy : (ok2 ? -dy : 0);
-                const float clip_w = ok1 ? n1.x : (ok2 ? n2.x : w_own[j]);
-                const bool contributes = dilated | covered[j];
-
+                const bool pos = ((xs + j + y) & 1) == 0;                       // first attempt towards +x / up (:191), else -x / down
+                const bool ok_a = horiz ? (pos ? ok_r[j] : ok_l[j]) : (pos ? ok_u[j] : ok_d[j]);
+                const bool ok_b = horiz ? (pos ? ok_l[j] : ok_r[j]) : (pos ? ok_d[j] : ok_u[j]);
+                const bool dilated = ok_a | ok_b;                                // the opposite direction if the first failed (:192-193)
+                const bool fwd = pos == ok_a;                                    // the neighbour taken lies at +x / up
+                const float w_h = fwd ? (j == 3 ? w_r : w_own[j == 3 ? 3 : j + 1]) : (j == 0 ? w_l : w_own[j == 0 ? 0 : j - 1]);
+                const float w_v = fwd ? w_up[j] : w_dn[j];
+                const float clip_w = dilated ? (horiz ? w_h : w_v) : w_own[j];
                 if constexpr (DEBUG) {
-                    if (c_begin == 0 && in_px[j]) write_debug(p.debug_thingy, p.grad_pixels, p.B, H, W, C, iib, y, xj, G, dilated);
+                    if (c0 == 0 && gi == 0 && in_px[j]) write_debug(p.debug_thingy, p.grad_pixels, p.B, H, W, C, iib, y, xs + j, G0, dilated);
                 }
-
-                // clip-space x,y of the fragment used (:210-215 sums b_k * vertex_k.xy; perspective-correct
-                // barycentrics make that sum the fragment's own clip position = its NDC position times clip_w, so no
-                // vertex gather is needed; agrees to float rounding).  :219-222 with one reciprocal (v_rcp_f32, 1 ulp):
-                //   gx = dL_dx * b_k * (W/2) / w ; gy likewise ; gw = -(gx * ndc_x + gy * ndc_y)
-                const float ndc_x = ((float)(xj + ddx) + 0.5f) * (2.f / width_f) - 1.f;
-                const float ndc_y = ((float)(H - 1 - (y + ddy)) + 0.5f) * (2.f / height_f) - 1.f;
                 const float rcp_w = __builtin_amdgcn_rcpf(clip_w);
+                const bool contributes = dilated | covered[j];
                 const float fx = contributes ? (dLx[gi][j] * (.5f * width_f)) * rcp_w : 0.f;
                 const float fy = contributes ? (dLy[gi][j] * (.5f * height_f)) * rcp_w : 0.f;
-                const float fw = -(fx * ndc_x + fy * ndc_y);
-                if (!dilated) { fpos[j][0] += fx; fpos[j][1] += fy; fpos[j][2] += fw; }
-
-                // dilated pairs take the neighbour's face and barycentrics: list them for the face loop
-                const unsigned long long dm = __builtin_amdgcn_ballot_w64(dilated);
-                if (dm != 0ull) {
-                    const uint32_t e = nlist + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-                    const float4 nsel = ok1 ? n1 : n2;
-                    const uint32_t trel = (uint32_t)((int)own_rel + j + ddy * W + ddx);  // the neighbour, relative to (row0, 0)
-                    if (dilated && e < (uint32_t)LCAP) {
-                        float* ep = entry_ptr(e);
-                        *reinterpret_cast<float4*>(ep) = make_float4(nsel.y, nsel.z, nsel.w, __uint_as_float(trel));
-                        *reinterpret_cast<float4*>(ep + 4) = make_float4(fx, fy, fw, 0.f);
-                    }
-                    nlist += (uint32_t)__popcll(dm);
-                    if (nlist > (uint32_t)LCAP) {  // list full (many dilated pairs in one wave): the reference's direct float atomics
-                        if (dilated && e >= (uint32_t)LCAP) {
-                            const float2 nb = ld_off<float2>(state_t, trel * 16u);
-                            const float bb[3] = {nb.x, nb.y, (1.f - nb.x) - nb.y};
-                            const int vi[3] = {__float_as_int(nsel.y), __float_as_int(nsel.z), __float_as_int(nsel.w)};
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                float* gv = grad_vertices + (size_t)vi[k] * 4;
-                                atomicAdd(gv + 0, fx * bb[k]);
-                                atomicAdd(gv + 1, fy * bb[k]);
-                                atomicAdd(gv + 3, fw * bb[k]);
-                            }
-                        }
-                        nlist = (uint32_t)LCAP;
-                    }
+                fpos[j][0] += dilated ? 0.f : fx;
+                fpos[j][1] += dilated ? 0.f : fy;
+                if (dilated) {  // few lanes: ds_add_f32 into the neighbour's cell
+                    const int step = horiz ? 1 : -IS;                            // +x, or up = the previous row
+                    float* cell = reinterpret_cast<float*>(inbox + (my_cell + j + (fwd ? step : -step)));
+                    atomicAdd(cell, fx);
+                    atomicAdd(cell + 1, fy);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
-
-        // ---- the list, one entry per lane ----
-        int lkey[3] = {-1, -1, -1};
-        float lb[3] = {0.f, 0.f, 0.f}, lf[3] = {0.f, 0.f, 0.f};
-        if ((uint32_t)lane < nlist) {
-            const float* ep = entry_ptr((uint32_t)lane);
-            const float4 a = *reinterpret_cast<const float4*>(ep), f = *reinterpret_cast<const float4*>(ep + 4);
-            lkey[0] = __float_as_int(a.x); lkey[1] = __float_as_int(a.y); lkey[2] = __float_as_int(a.z);
-            const float2 nb = ld_off<float2>(state_t, __float_as_uint(a.w) * 16u);
-            lb[0] = nb.x; lb[1] = nb.y; lb[2] = (1.f - nb.x) - nb.y;
-            lf[0] = f.x; lf[1] = f.y; lf[2] = f.z;
+        GMARK();  // 5 dilation done
+        // what the neighbours sent to this strip, and fw of the totals
+        {
+            const float4 i01 = *reinterpret_cast<const float4*>(inbox + my_cell), i23 = *reinterpret_cast<const float4*>(inbox + my_cell + 2);
+            fpos[0][0] += i01.x; fpos[0][1] += i01.y; fpos[1][0] += i01.z; fpos[1][1] += i01.w;
+            fpos[2][0] += i23.x; fpos[2][1] += i23.y; fpos[3][0] += i23.z; fpos[3][1] += i23.w;
         }
+        const float ndc_y_own = ((float)(H - 1 - y) + 0.5f) * (2.f / height_f) - 1.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bk[j][2] = (1.f - bk[j][0]) - bk[j][1];
+        for (int j = 0; j < 4; ++j) {
+            const float ndc_x = ((float)(xs + j) + 0.5f) * (2.f / width_f) - 1.f;
+            fpos[j][2] = -(fpos[j][0] * ndc_x + fpos[j][1] * ndc_y_own);
+        }
+        // ---- the ring: what this wave's pixels sent to pixels of other waves (the row above / below the region, the column
+        //      left / right of the tile).  Those pixels' faces take it through the face loop, at most two ring cells per
+        //      lane: cells 0-33 the row above, 34-67 the row below, 68-75 / 76-83 the columns left / right. ----
+        int lkey[2];
+        float lb[2][3], lf[2][3];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = lane + 64 * e;
+            const bool top = r < 34, bottom = r >= 34 && r < 68, left = r >= 68 && r < 76;
+            const int ty = top ? -1 : (bottom ? 8 : (left ? r - 68 : r - 76));
+            const int tx = top ? r - 1 : (bottom ? r - 35 : (left ? -1 : 32));
+            lkey[e] = -1;
+            lb[e][0] = 0.f; lb[e][1] = 0.f; lb[e][2] = 0.f; lf[e][0] = 0.f; lf[e][1] = 0.f; lf[e][2] = 0.f;
+            if (r < RING) {
+                const float2 v = inbox[(ty + 1) * IS + tx + 2];
+                if (v.x != 0.f || v.y != 0.f) {  // only pixels inside the frame are ever sent anything
+                    const int py = y0 + 8 * wave + ty, px = x0 + tx;
+                    lkey[e] = __float_as_int(s_vw[8 * wave + ty + 1][tx + 2].y);
+                    const float2 nb = ld_off<float2>(state_b, (uint32_t)((py - row0) * W + px) * 8u);
+                    lb[e][0] = nb.x; lb[e][1] = nb.y; lb[e][2] = (1.f - nb.x) - nb.y;
+                    const float ndc_x = ((float)px + 0.5f) * (2.f / width_f) - 1.f;
+                    const float ndc_y = ((float)(H - 1 - py) + 0.5f) * (2.f / height_f) - 1.f;
+                    lf[e][0] = v.x; lf[e][1] = v.y; lf[e][2] = -(v.x * ndc_x + v.y * ndc_y);
+                }
+            }
+        }
+        GCOUNT(0, __popcll(__builtin_amdgcn_ballot_w64(lkey[0] >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(lkey[1] >= 0)));
 
-        // ---- this lane's role in the face loop: lane 16 r + c (c < NV4/4) adds value v = c + (NV4/4) r of the face:
+        // ---- this lane's role in the face loop: it adds value role_v of the face (reduce_value_of_lane):
         //      v < 9: component v % 3 (x, y, w) of grad_vertices of vertex v / 3; else colour (v - 9) % NCH of vertex
         //      (v - 9) / NCH ----
-        const int role_v = (lane & 15) + (NV4 / 4) * (lane >> 4);
-        const bool role_valid = (lane & 15) < NV4 / 4 && role_v < NV;
+        const int role_v = reduce_value_of_lane<NR>(lane);
+        const bool role_valid = role_v >= 0 && role_v < NV;
         const bool role_pos = role_v < 9;
         const int role_k = role_pos ? role_v / 3 : (role_v - 9) / NCH;
         const int role_e = role_pos ? (role_v % 3 == 2 ? 3 : role_v % 3) : c0 + (role_v - 9) % NCH;
         float* const role_base = role_pos ? grad_vertices + role_e : grad_vertex_colors + role_e;
         const uint32_t role_stride = role_pos ? 16u : pixel_bytes;
 
-        // ---- the face loop: pending pixels / list entries as wave-wide masks (scalar registers) ----
-        unsigned long long pend[5];
+        // ---- the face loop: pending pixels / ring cells as wave-wide masks (scalar registers) ----
+        unsigned long long pend[6];
 #pragma unroll
         for (int j = 0; j < 4; ++j) pend[j] = __builtin_amdgcn_ballot_w64(covered[j]);
         pend[4] = __builtin_amdgcn_ballot_w64(lkey[0] >= 0);
+        pend[5] = __builtin_amdgcn_ballot_w64(lkey[1] >= 0);
+        GMARK();  // 6 face loop starts
         for (;;) {
-            int K0, K1, K2;
-            {
-                int src;
-                if (pend[0]) { src = __ffsll((long long)pend[0]) - 1; K0 = __builtin_amdgcn_readlane(key[0][0], src); K1 = __builtin_amdgcn_readlane(key[0][1], src); K2 = __builtin_amdgcn_readlane(key[0][2], src); }
-                else if (pend[1]) { src = __ffsll((long long)pend[1]) - 1; K0 = __builtin_amdgcn_readlane(key[1][0], src); K1 = __builtin_amdgcn_readlane(key[1][1], src); K2 = __builtin_amdgcn_readlane(key[1][2], src); }
-                else if (pend[2]) { src = __ffsll((long long)pend[2]) - 1; K0 = __builtin_amdgcn_readlane(key[2][0], src); K1 = __builtin_amdgcn_readlane(key[2][1], src); K2 = __builtin_amdgcn_readlane(key[2][2], src); }
-                else if (pend[3]) { src = __ffsll((long long)pend[3]) - 1; K0 = __builtin_amdgcn_readlane(key[3][0], src); K1 = __builtin_amdgcn_readlane(key[3][1], src); K2 = __builtin_amdgcn_readlane(key[3][2], src); }
-                else if (pend[4]) { src = __ffsll((long long)pend[4]) - 1; K0 = __builtin_amdgcn_readlane(lkey[0], src); K1 = __builtin_amdgcn_readlane(lkey[1], src); K2 = __builtin_amdgcn_readlane(lkey[2], src); }
-                else break;
-            }
-            float acc[NV4];
+            int K;
+            if (pend[0]) K = __builtin_amdgcn_readlane(key[0], __ffsll((long long)pend[0]) - 1);
+            else if (pend[1]) K = __builtin_amdgcn_readlane(key[1], __ffsll((long long)pend[1]) - 1);
+            else if (pend[2]) K = __builtin_amdgcn_readlane(key[2], __ffsll((long long)pend[2]) - 1);
+            else if (pend[3]) K = __builtin_amdgcn_readlane(key[3], __ffsll((long long)pend[3]) - 1);
+            else if (pend[4]) K = __builtin_amdgcn_readlane(lkey[0], __ffsll((long long)pend[4]) - 1);
+            else if (pend[5]) K = __builtin_amdgcn_readlane(lkey[1], __ffsll((long long)pend[5]) - 1);
+            else break;
+            // the face's vertex indices (a wave-uniform address: requested now, needed after the reduction)
+            const int32_t* fk = faces + (size_t)(uint32_t)K * 3;
+            const int v0 = fk[0], v1 = fk[1], v2 = fk[2];
+            float acc[NR];
 #pragma unroll
-            for (int v = NV; v < NV4; ++v) acc[v] = 0.f;
+            for (int v = NV; v < NR; ++v) acc[v] = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool m = (key[j][0] == K0) & (key[j][1] == K1) & (key[j][2] == K2);
+                const bool m = key[j] == K;
                 pend[j] &= ~__builtin_amdgcn_ballot_w64(m);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -587,21 +642,23 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
                         acc[9 + NCH * k + ch] = j == 0 ? bm * g[j][ch] : fmaf(bm, g[j][ch], acc[9 + NCH * k + ch]);
                 }
             }
-            {
-                const bool m = (lkey[0] == K0) & (lkey[1] == K1) & (lkey[2] == K2);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const bool m = lkey[e] == K;
                 const unsigned long long mm = __builtin_amdgcn_ballot_w64(m);
                 if (mm != 0ull) {
-                    pend[4] &= ~mm;
+                    pend[4 + e] &= ~mm;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const float bm = m ? lb[k] : 0.f;
+                        const float bm = m ? lb[e][k] : 0.f;
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) acc[3 * k + c] = fmaf(bm, lf[c], acc[3 * k + c]);
+                        for (int c = 0; c < 3; ++c) acc[3 * k + c] = fmaf(bm, lf[e][c], acc[3 * k + c]);
                     }
                 }
             }
-            const float total = wave_reduce_scatter<NV4>(acc, lane);
-            const int vsel = role_k == 0 ? K0 : (role_k == 1 ? K1 : K2);
+            GCOUNT(1, 1);
+            const float total = wave_reduce_scatter<NR>(acc, lane);
+            const int vsel = role_k == 0 ? v0 : (role_k == 1 ? v1 : v2);
             if (role_valid && total != 0.f)
                 atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(role_base) + (size_t)((uint32_t)vsel * role_stride)), total);
         }
@@ -621,8 +678,19 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
         }
         c0 += nch;
         if (CSPEC) break;  // a single pass, statically
-        if (c0 < C) __syncthreads();  // every wave is done with the planes (and with its list inside them)
+        if (c0 < C) {
+            zero_inbox();     // this wave's own; nobody else touches it
+            __syncthreads();  // every wave is done with the planes
+        }
     }
+    GMARK();  // 7 done
+#ifdef DIRT_TRACE
+    if (lane == 0 && g_trace_grad) {
+        long long* o = g_trace_grad + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16;
+        for (int i = 0; i < 12; ++i) o[i] = i < tr_n ? tr_t[i] : 0;
+        o[12] = tr_c[0]; o[13] = tr_c[1];
+    }
+#endif
 }
 
 hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)

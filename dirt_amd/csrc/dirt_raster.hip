@@ -265,26 +265,28 @@ __device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec
     }
 }
 
-// The backward pass's state of one pixel, {b0, b1, clip_w, face}: csrc/shaders.cpp:64-77 (b2 = 1 - b0 - b1; the face
-// index stands for the index triple); the clear values of csrc/rasterise_grad_egl.cpp:442-445 where nothing is covered.
-__device__ __forceinline__ float4 state_clear() { return make_float4(-1.f, -1.f, INFINITY, __int_as_float(-1)); }
+// The backward pass's state of one pixel -- csrc/shaders.cpp:64-77: {clip_w, face} and {b0, b1} (b2 = 1 - b0 - b1; the
+// face index stands for the index triple) -- or the clear values of csrc/rasterise_grad_egl.cpp:442-445.
+__device__ __forceinline__ void store_state(const RasterParams& p, size_t pix, float b0, float b1, float clip_w, int32_t face)
+{
+    p.state_a[pix] = make_float2(clip_w, __int_as_float(face));
+    p.state_b[pix] = make_float2(b0, b1);
+}
 
 __device__ __forceinline__ void export_state(const RasterParams& p, const FaceRec* __restrict__ recs, int ib, int x, int r,
                                              double px, double py, int32_t f)
 {
-    float4 st = state_clear();
-    if (f >= 0) {
-        const FaceRec* __restrict__ rec = recs + f;
-        double cf[9];
+    const size_t pix = ((size_t)ib * p.H + r) * p.W + x;
+    if (f < 0) { store_state(p, pix, -1.f, -1.f, INFINITY, -1); return; }
+    const FaceRec* __restrict__ rec = recs + f;
+    double cf[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) cf[k] = rec->coef[k];
-        double Fk[3];
-        edge_eval(cf, px, py, Fk);
-        float b[3], cw;
-        bary_eval(Fk, rec->flags, rec->inv_det, b, cw);
-        st = make_float4(b[0], b[1], cw, __int_as_float(f));
-    }
-    p.state[((size_t)ib * p.H + r) * p.W + x] = st;
+    for (int k = 0; k < 9; ++k) cf[k] = rec->coef[k];
+    double Fk[3];
+    edge_eval(cf, px, py, Fk);
+    float b[3], cw;
+    bary_eval(Fk, rec->flags, rec->inv_det, b, cw);
+    store_state(p, pix, b[0], b[1], cw, f);
 }
 
 // Shade one pixel: the winner's record is re-read, barycentrics and all C channels interpolated once.
@@ -296,7 +298,7 @@ __device__ __forceinline__ void shade_pixel(const RasterParams& p, const FaceRec
     const int C = CSPEC ? CSPEC : p.C;  // CSPEC = 1, 3, 4: compile-time channel count; 0: any
     float* __restrict__ out = p.pixels + pix * C;
     if (f < 0) {  // pixels start as the background: csrc/rasterise_egl.cpp:348-356
-        if (p.state) p.state[pix] = state_clear();
+        if (p.state_a) store_state(p, pix, -1.f, -1.f, INFINITY, -1);
         const float* __restrict__ bg = p.background + pix * C;
         if ((C & 3) == 0) {
             for (int c = 0; c < C; c += 4)
@@ -314,7 +316,7 @@ __device__ __forceinline__ void shade_pixel(const RasterParams& p, const FaceRec
     edge_eval(cf, px, py, Fk);
     float b[3], cw;
     bary_eval(Fk, rec->flags, rec->inv_det, b, cw);
-    if (p.state) p.state[pix] = make_float4(b[0], b[1], cw, __int_as_float(f));
+    if (p.state_a) store_state(p, pix, b[0], b[1], cw, f);
     const float* __restrict__ cols = p.vertex_colors + (size_t)ib * p.V * C;
     const float* __restrict__ c0 = cols + (size_t)rec->vid[0] * C;
     const float* __restrict__ c1 = cols + (size_t)rec->vid[1] * C;
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(NB == 1 ? 2 * RTHREADS : RTHREADS) void raster_kern
         const int32_t f = s_vis[i];
         if (p.vis) p.vis[((size_t)ib * p.H + r) * p.W + x] = f;
         if (MODE == 0) shade_pixel<CSPEC>(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
-        else if (p.state) export_state(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
+        else if (p.state_a) export_state(p, recs, ib, x, r, (double)x + 0.5, (double)(p.H - 1 - r) + 0.5, f);
     }
     TRACE_MARK();  // 7: stored
 #ifdef DIRT_TRACE
