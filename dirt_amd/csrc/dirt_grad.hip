@@ -54,8 +54,8 @@ constexpr int PR = GT + 2;              // staged rows: y0-1 .. y0+32
 constexpr int PS = 36;                  // plane row stride (floats): column (x - x0) for x0 .. x0+34, column 35 holds x0-1
 constexpr int VS = 36;                  // state tile row stride (float2): column (x - x0) + 2, so that strips are 16-byte aligned
 constexpr int PC = 4;                   // channels per pass: whole channel groups that fit in 4 channels
-constexpr int IS = 36;                  // inbox row stride (float2 cells): cell (ty + 1) * 36 + tx + 2 for ty in -1..8, tx in -1..32
-constexpr int ICELLS = 10 * IS;         // ... of a wave's 32 x 8 region and the one-pixel ring around it
+constexpr int IS = 34;                  // inbox row stride (float2 cells): cell (ty + 1) * 34 + tx + 2 for ty in -1..8, tx in -1..32
+constexpr int ICELLS = 10 * IS + 4;     // ... of a wave's 32 x 8 region and the one-pixel ring around it (a multiple of 2: 16-byte cells pairs)
 constexpr int RING = 2 * 34 + 2 * 8;    // ring cells: what the wave's pixels sent to pixels of other waves
 
 // Reduce N (16 or 24) per-lane values across the 64 lanes of the wave: a transposing butterfly.  Inside a DPP row of 16
@@ -115,45 +115,48 @@ __device__ __forceinline__ int reduce_value_of_lane(int lane)
     return -1;
 }
 
-// Scharr responses of one channel from global memory for an aliased (quirk Q1) channel whose taps run past the
-// end of the image row: the tap centre is pixel (row y, column x) of scene iib, `shift` elements further on in the
-// flattened [B,H,W] slice; reads past the end of the tensor are clamped to its last element (undefined in the
-// reference).  Rare (only the last columns of a frame): used by alias_wrap_fixup only.
-__device__ __forceinline__ float2 scharr_taps_wrapped(const float* __restrict__ pixels, int B, int H, int W, int C, int iib, int y,
-                                                  int x, int shift, int c)
-{
-    const size_t total_pix = (size_t)B * H * W;
-    const size_t centre = ((size_t)iib * H + y) * W + x + shift;
-    float sx, sy;
-    auto at = [&](int ox, int oy) {
-        size_t m = centre + (size_t)ox - (size_t)((long long)oy * W);  // offset_y up = previous row
-        if (m > total_pix - 1) m = total_pix - 1;
-        return pixels[m * C + c];
-    };
-    float d1 = ((at(-1, -1) + at(-1, +1)) - at(+1, -1)) - at(+1, +1);
-    float d2 = at(-1, 0) - at(+1, 0);
-    float m1 = d1 * (3.f / 32.f), m2 = d2 * (10.f / 32.f);
-    sx = m1 + m2;
-    d1 = ((at(-1, -1) + at(+1, -1)) - at(-1, +1)) - at(+1, +1);
-    d2 = at(0, -1) - at(0, +1);
-    m1 = d1 * (3.f / 32.f); m2 = d2 * (10.f / 32.f);
-    sy = m1 + m2;
-    return make_float2(sx, sy);
-}
-
 // Quirk Q1 at the right image border: for the pixels of a strip (first column xs, row y) flagged in `which`, the
-// aliased "channels" 1, 2 of 1-channel group c lie in the next image row; their dilation axis (:185) is decided again
-// from global memory and replaces bits shift .. shift+3 of `bits`.  Rare: a rolled loop behind a wave-uniform branch.
+// aliased "channels" 1, 2 of 1-channel group c -- elements (pixel + 1, + 2) of the flattened [B,H,W,1] slice -- lie in
+// the NEXT image row (past the end of the tensor they are clamped to its last element; undefined in the reference).
+// Their dilation axis (:185) is decided again from memory -- the 5 x 3 window of elements the three Scharr stencils
+// cover, requested together -- and replaces bits shift .. shift+3 of `bits`.  Rare (the last two interior columns of a
+// frame): a rolled loop behind a wave-uniform branch.
 __device__ __forceinline__ uint32_t alias_wrap_fixup(const float* __restrict__ pixels, int B, int H, int W, int C, int iib, int y,
                                                   int xs, int c, uint32_t which, uint32_t bits, int shift)
 {
+    const size_t last = (size_t)B * H * W - 1;
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) {
         if (!((which >> j) & 1u)) continue;
-        const float2 s0 = scharr_taps_wrapped(pixels, B, H, W, C, iib, y, xs + j, 0, c);
-        const float2 s1 = scharr_taps_wrapped(pixels, B, H, W, C, iib, y, xs + j, 1, c);
-        const float2 s2 = scharr_taps_wrapped(pixels, B, H, W, C, iib, y, xs + j, 2, c);
-        const float l1x = (fabsf(s0.x) + fabsf(s1.x)) + fabsf(s2.x), l1y = (fabsf(s0.y) + fabsf(s1.y)) + fabsf(s2.y);
+        // w[r][i]: element (centre + i - 1) of row y - 1 + r in flat order; at(ox, oy) of "channel" ch = w[1 - oy][ch + 1 + ox]
+        float w[3][5];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const size_t base = ((size_t)iib * H + (y - 1 + r)) * W + xs + j - 1;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                size_t m = base + i;
+                if (m > last) m = last;
+                w[r][i] = pixels[m * C + c];
+            }
+        }
+        float l1x = 0.f, l1y = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float mm = w[2][ch], m0 = w[1][ch], mp = w[0][ch];
+            const float zm = w[2][ch + 1], zp = w[0][ch + 1];
+            const float pm = w[2][ch + 2], p0 = w[1][ch + 2], pp = w[0][ch + 2];
+            float d1 = ((mm + mp) - pm) - pp;
+            float d2 = m0 - p0;
+            float m1 = d1 * (3.f / 32.f), m2 = d2 * (10.f / 32.f);
+            const float sx = m1 + m2;
+            d1 = ((mm + pm) - mp) - pp;
+            d2 = zm - zp;
+            m1 = d1 * (3.f / 32.f); m2 = d2 * (10.f / 32.f);
+            const float sy = m1 + m2;
+            l1x = ch == 0 ? fabsf(sx) : l1x + fabsf(sx);
+            l1y = ch == 0 ? fabsf(sy) : l1y + fabsf(sy);
+        }
         bits = (bits & ~(1u << (shift + j))) | ((l1x > l1y) ? (1u << (shift + j)) : 0u);
     }
     return bits;
@@ -203,8 +206,15 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
 
 #ifdef DIRT_TRACE
     long long tr_t[12]; int tr_n = 0; long long tr_c[4] = {0, 0, 0, 0};
+    const long long tr_wall0 = wall_clock64();
 #endif
     GMARK();  // 0 start
+#ifdef DIRT_STAGGER
+    {   // experiment: offset the workgroups that share a CU in time, so that their memory and compute phases interleave
+        const int slot = DIRT_STAGGER_MAP;
+        for (int i = 0; i < slot * DIRT_STAGGER; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -291,11 +301,11 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
                 if (ch < nch) s_pix[ch][row][col] = v[k][ch];
         }
     };
-    auto zero_inbox = [&]() {  // 360 cells: six per lane of the first sixty
-        if (lane < ICELLS / 6) {
-            float4* z = reinterpret_cast<float4*>(inbox + 6 * lane);
-            z[0] = make_float4(0.f, 0.f, 0.f, 0.f); z[1] = make_float4(0.f, 0.f, 0.f, 0.f); z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    auto zero_inbox = [&]() {  // 344 cells = 172 pairs
+        float4* z = reinterpret_cast<float4*>(inbox);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (lane + 64 * i < ICELLS / 2) z[lane + 64 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
     // ---- phase A: the visibility "surface" of the tile + 1-pixel halo -- what the backward fragment shader writes
@@ -689,6 +699,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
         long long* o = g_trace_grad + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16;
         for (int i = 0; i < 12; ++i) o[i] = i < tr_n ? tr_t[i] : 0;
         o[12] = tr_c[0]; o[13] = tr_c[1];
+        o[14] = tr_wall0; o[15] = ((long long)wall_clock64() << 20) | (long long)(__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4 /* HW_REG_HW_ID */) & 0xFFFFF);
     }
 #endif
 }

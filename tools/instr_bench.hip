@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <vector>
 
-#define REP 256
+#define REP 1024
 
 template <int KIND>
 __device__ __forceinline__ void op(float& a, float& b)
@@ -46,6 +46,7 @@ __global__ void k(float* out, long long* cyc)
     for (int i = 0; i < 4; ++i) { a[i] = (float)threadIdx.x + i; b[i] = 0.25f * i; }
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(a[i]), "+v"(b[i]));
     long long t0, t1;
+    const long long w0 = wall_clock64();
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(a[i]), "+v"(b[i]));
 #pragma unroll
@@ -57,23 +58,26 @@ __global__ void k(float* out, long long* cyc)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(a[i]), "+v"(b[i]));
     out[blockIdx.x * blockDim.x + threadIdx.x] = a[0] + a[1] + a[2] + a[3];
-    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+    const long long w1 = wall_clock64();
+    if ((threadIdx.x & 63) == 0) { cyc[2 * (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64)] = t1 - t0; cyc[2 * (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) + 1] = w1 - w0; }
 }
 
 template <int KIND>
 void run(const char* name)
 {
     float* out; long long* cyc;
-    hipMalloc(&out, 4 * 1024 * 1024); hipMalloc(&cyc, 8 * 16384);
+    hipMalloc(&out, 4 * 1024 * 1024); hipMalloc(&cyc, 16 * 16384);
     for (int cfg = 0; cfg < 2; ++cfg) {
         const int blocks = cfg == 0 ? 1 : 256 * 4, threads = cfg == 0 ? 64 : 256;  // one wave; 4 waves per SIMD on every CU
         hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), 0, 0, out, cyc);
         hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), 0, 0, out, cyc);
         hipDeviceSynchronize();
-        std::vector<long long> h(blocks * threads / 64);
+        std::vector<long long> h(2 * blocks * threads / 64);
         hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
-        double s = 0; for (auto v : h) s += (double)v;
-        printf("%-28s %s: %.1f clocks per op (per wave)\n", name, cfg == 0 ? "1 wave      " : "4 waves/SIMD", s / h.size() / (REP * 4));
+        double s = 0, w = 0; for (size_t i = 0; i < h.size(); i += 2) { s += (double)h[i]; w += (double)h[i + 1]; }
+        const double nw = h.size() / 2;
+        printf("%-28s %s: %.1f s_memtime ticks, %.2f ns per op per wave (wall clock)\n", name, cfg == 0 ? "1 wave      " : "4 waves/SIMD",
+               s / nw / (REP * 4), w / nw * 10.0 / (REP * 4));
     }
     hipFree(out); hipFree(cyc);
 }

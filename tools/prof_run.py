@@ -1,4 +1,4 @@
-import sys, os; sys.path.insert(0, '.')
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from dirt_amd import scenes, rasterise_ops as ops
 dev = torch.device('cuda:0')

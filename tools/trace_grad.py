@@ -31,3 +31,23 @@ print('  %-26s %9.0f %9.0f %9.0f' % ('total', tot.mean(), np.median(tot), tot.ma
 print('  dilated pairs listed per wave: mean %.1f max %d;  face-loop iterations per wave: mean %.1f max %d' % (a[:, 12].mean(), a[:, 12].max(), a[:, 13].mean(), a[:, 13].max()))
 print('  face loop clocks per iteration: %.0f' % (d[:, 6].sum() / max(1, a[:, 13].sum())))
 print('  kernel span (first start .. last end, clocks; not comparable across CUs): %d' % (tt[:, 7].max() - tt[:, 0].min()))
+
+w0 = a[:, 14].astype(np.float64); w1 = (a[:, 15] >> 20).astype(np.float64)
+t0 = w0.min()
+print('  wall clock (100 MHz): wave starts %.2f .. %.2f us after the first; ends %.2f .. %.2f us; wave duration mean %.2f us' % (
+    0.0, (w0.max() - t0) / 100.0, (w1.min() - t0) / 100.0, (w1.max() - t0) / 100.0, ((w1 - w0).mean()) / 100.0))
+st = np.sort((w0 - t0) / 100.0)
+print('  start-time percentiles (us): 50%% %.2f  75%% %.2f  90%% %.2f  99%% %.2f' % tuple(np.percentile(st, [50, 75, 90, 99])))
+hw = (a[:, 15] & 0xFFFFF).astype(np.int64)
+cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; simd = (hw >> 4) & 3
+blk = np.arange(len(a)) // 4
+key = se * 32 + sh * 16 + cu
+print('  placement (XCD 0 = blocks 0, 8, 16, ...): block -> (se, sh, cu) of its first wave')
+sel = [b for b in range(0, 8 * 140, 8)]
+print('   ', ' '.join('%d:%d.%d.%d' % (b, se[4 * b], sh[4 * b], cu[4 * b]) for b in sel[:48]))
+from collections import defaultdict
+g = defaultdict(list)
+for b in range(0, len(a) // 4, 8):
+    g[int(key[4 * b])].append(b)
+print('    blocks sharing a CU on XCD 0:', [v for v in list(g.values())[:6]])
+print('    SIMD of the 4 waves of block 0 / 8 / 16:', simd[0:4], simd[32:36], simd[64:68])
