@@ -30,7 +30,8 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec ...
+HBM_COPY_GBPS = 6290.0  # ... and 6.29 TB/s measured float4 copy (SURVEY.md 8d asks for the fraction against both)
 
 
 def algorithmic_bytes(P, V, F, C):
@@ -52,16 +53,34 @@ def kernel_algorithmic_bytes(P, V, F, C):
     }
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        return s_.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--scenes-per-gpu', type=int, default=1)
+    ap.add_argument('--scenes-per-gpu', type=int, default=0,
+                    help='scenes rendered per rank and step (default: 1 on one GPU = K3 itself; 8 on several = K4, 64 scenes over 8 GPUs)')
     ap.add_argument('--config', default='K3', help='K3 | K3-256 | K3-2048 | K5')
+    ap.add_argument('--launch', default='auto', choices=['auto', 'eager', 'graph'],
+                    help='how the timed steps are issued: eagerly, as one captured hipGraph replayed per step, or whichever a short calibration finds faster')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start N ranks on this node ourselves (one process per GPU,
+    # torch.distributed over RCCL); under torch.distributed.run (the driver's way) WORLD_SIZE is already set.
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        import subprocess
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % args.gpus,
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -71,16 +90,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     distributed = world > 1
+    ranks_seen = 1
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)            # proof that RCCL sees every rank; outside the timed region
+        ranks_seen = int(ones.item())
 
     from dirt_amd import scenes, _lib, rasterise_ops as ops
     _lib.load()
 
     F, H, W, C, seed0, r_lo, r_hi = scenes.CONFIGS[args.config]
-    spg = args.scenes_per_gpu
+    spg = args.scenes_per_gpu or (8 if distributed else 1)
     seeds = [seed0 + rank * spg + i for i in range(spg)]
     batch = scenes.batch_scene(F, H, W, C, seeds, r_lo=r_lo, r_hi=r_hi)
     V = batch['vertices'].shape[1]
@@ -102,19 +125,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Launch mode of the timed loop: the steps issued eagerly through the Python wrapper, or ONE captured hipGraph of the
+    # step (set-up + raster + gradient kernels on fixed buffers: the static-shape training-loop deployment) replayed per
+    # step -- the same launches either way.  Unless one is asked for, a short calibration inside the warm-up picks the
+    # faster (eager while the GPU is the limit, the graph once the host paces the launches).
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - c0) / n
+
+    graph_replay = None
+    if args.launch != 'eager':
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = step()
+        graph_replay = graph.replay
+    calib = {}
+    if args.launch == 'auto':
+        for _ in range(5):
+            step(); graph_replay()
+        calib = {'eager_ms_per_step': timed(step, 20) * 1e3, 'graph_ms_per_step': timed(graph_replay, 20) * 1e3}
+        use_graph = calib['graph_ms_per_step'] < calib['eager_ms_per_step']
+        if distributed:  # every rank takes rank 0's choice
+            flag = torch.tensor([1 if use_graph else 0], device=dev)
+            dist.broadcast(flag, src=0)
+            use_graph = bool(flag.item())
+    else:
+        use_graph = args.launch == 'graph'
+    run = graph_replay if use_graph else step
+
     for _ in range(args.warmup):
-        step()
+        run()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-
     ms_per_step = elapsed / args.steps * 1e3
     total_pixels = world * spg * P
     value = total_pixels / (elapsed / args.steps) / 1e6
@@ -138,16 +199,21 @@ def main():
         avg_s = kernels[dom]['avg_us'] * 1e-6
         per_launch = kbytes[dom] * spg
         achieved = per_launch / avg_s / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')  # written by tools/pmc_summary.py from rocprofv3 --pmc passes
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.config, {}).get(dom)
+                pj = json.load(open(pmc))
+                traffic = pj.get(args.config, {}).get(dom)
+                if traffic is not None:
+                    traffic_source = 'profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run' % pj.get('_collected', 'committed')
             except Exception:
                 traffic = None
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                    'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                    'algorithmic_bytes_per_launch': per_launch, 'avg_launch_us': kernels[dom]['avg_us']}
+                    'frac': achieved / HBM_PEAK_GBPS, 'frac_of_measured_copy_peak': achieved / HBM_COPY_GBPS,
+                    'traffic': traffic, 'traffic_source': traffic_source,
+                    'algorithmic_bytes_per_launch': per_launch, 'avg_launch_us': kernels[dom]['avg_us'],
+                    'timing': 'HIP events recorded by the library around each launch on its stream (DIRT_FLAG_PROFILE), eager steps'}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N == 1) ----
     cpu_baseline = None
@@ -195,11 +261,15 @@ def main():
             'dtype': 'f32 (f64 edge functions)', 'data': 'synthetic',
             'config': {'workload': '%s: rand_mesh F=%d at %dx%dx%d, %d scene(s) per GPU, forward+backward'
                                    % (args.config, F, H, W, C, spg),
-                       'scenes_per_gpu': spg, 'parallelism': 'batch-sharded x%d, no collective' % world},
+                       'scenes_per_gpu': spg, 'parallelism': 'batch-sharded x%d, no collective' % world,
+                       'launch': 'one captured hipGraph replayed per step' if use_graph else 'eager (Python wrapper + C ABI per step)'},
+            'ranks_seen': ranks_seen,
+            'launch_calibration': calib,
             'roofline': roofline,
             'roofline_step': {'algorithmic_bytes': step_bytes, 'achieved': step_bytes / (ms_per_step * 1e-3) / 1e9,
                               'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                              'frac': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                              'frac': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              'frac_of_measured_copy_peak': step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_COPY_GBPS},
             'kernels': kernels,
             'cpu_baseline': cpu_baseline,
         }

@@ -196,3 +196,91 @@ def hostile_scene(H, W, C, seed, n_small=200):
             'vertex_colors': rng.uniform(0, 1, (V, C)).astype(np.float32), 'faces': faces,
             'grad_pixels': rng.standard_normal((H, W, C)).astype(np.float32),
             'height': H, 'width': W, 'channels': C}
+
+
+def _perspective(near, far, right, aspect):
+    """dirt/matrices.py:110-153 `perspective_projection` (OpenGL convention, row vectors), numpy restatement."""
+    top = right * aspect
+    return np.array([[near / right, 0, 0, 0], [0, near / top, 0, 0],
+                     [0, 0, -(far + near) / (far - near), -2. * far * near / (far - near)], [0, 0, -1., 0]]).T
+
+
+def make_cylinder(radius, height, end_offset, bevel, segments):
+    """The bevelled cylinder of the reference's tests/rasterise_tests.py:11-47 (centred on the origin, axis along y):
+    returns (vertices [4 * segments + 2, 3], faces [8 * segments, 3])."""
+    angles = np.linspace(0., 2 * math.pi, segments, endpoint=False, dtype=np.float32)
+    xz = np.stack([np.cos(angles), np.sin(angles)], axis=1) * radius
+    ones = np.ones(segments)
+    top_bevel = np.stack([xz[:, 0] * (1. - bevel), ones * -height / 2. - radius * bevel, xz[:, 1] * (1. - bevel)], axis=1)
+    top = np.stack([xz[:, 0], ones * -height / 2., xz[:, 1]], axis=1)
+    bottom = np.stack([xz[:, 0], ones * height / 2., xz[:, 1]], axis=1)
+    bottom_bevel = np.stack([xz[:, 0] * (1. - bevel), ones * height / 2. + radius * bevel, xz[:, 1] * (1. - bevel)], axis=1)
+    ends = [[0., -height / 2. - end_offset, 0.], [0., height / 2. + end_offset, 0.]]
+    vertices = np.concatenate([top_bevel, top, bottom, bottom_bevel, ends], axis=0)
+    faces = []
+    for start in (0, segments, 2 * segments):
+        for q in range(segments):
+            u1, u2 = start + q, start + (q + 1) % segments
+            l1, l2 = u1 + segments, u2 + segments
+            faces.extend([[u1, u2, l1], [l1, u2, l2]])
+    for t1 in range(segments):
+        t2 = (t1 + 1) % segments
+        b1 = t1 + segments * 3
+        b2 = (b1 + 1) % segments      # (sic: tests/rasterise_tests.py:41)
+        faces.extend([[segments * 4, t1, t2], [segments * 4 + 1, b1, b2]])
+    return vertices, np.array(faces, dtype=np.int32)
+
+
+def cylinder_scene(translation=(0., 0., -0.25), rotation_xy=0., bgcolor=(0.4, 0.2, 0.2), vertex_color=(0.7, 0.3, 0.6), seed=0):
+    """The scene of the reference's tests/rasterise_tests.py:50-99: the cylinder `make_cylinder(0.2, 0.75, 0.1, 0., 10)`
+    split to 240 vertices, rotated about z and scaled by 0.5, translated, under `perspective_projection(0.1, 20., 0.2,
+    h / w)`, at 48 x 36 x 3; the first 75 vertices `vertex_color`, the rest random; the top half of the background
+    `bgcolor`, the bottom half white.  The arguments are the values the reference feeds (:115)."""
+    w, h = 48, 36
+    verts, faces = make_cylinder(0.2, 0.75, 0.1, 0., 10)
+    verts = np.concatenate([verts, np.ones([len(verts), 1])], axis=1)
+    verts = verts[faces.reshape(-1)]                                    # split_vertices_by_face (dirt/lighting.py:136-179)
+    faces = np.arange(len(verts), dtype=np.int32).reshape(-1, 3)
+    c, s = math.cos(rotation_xy), math.sin(rotation_xy)
+    view1 = np.array([[0.5 * c, -0.5 * s, 0, 0], [0.5 * s, 0.5 * c, 0, 0], [0, 0, 0.5, 0], [0, 0, 0, 1.]])
+    view2 = np.eye(4)
+    view2[3, :3] = translation
+    clip = verts @ view1 @ view2 @ _perspective(0.1, 20., 0.2, float(h) / w)
+    rng = np.random.default_rng(seed)
+    V = len(verts)
+    colors = np.concatenate([np.tile(np.asarray(vertex_color)[None], [75, 1]), rng.uniform(size=[V - 75, 3])], axis=0)
+    bg = np.concatenate([np.tile(np.asarray(bgcolor)[None, None], [h // 2, w, 1]), np.ones([h // 2, w, 3])], axis=0)
+    return dict(background=bg.astype(np.float32), vertices=clip.astype(np.float32), vertex_colors=colors.astype(np.float32),
+                faces=faces, grad_pixels=rng.standard_normal([h, w, 3]).astype(np.float32), height=h, width=w, channels=3)
+
+
+def cylinder_batch_scene(seed=0):
+    """The batch of two of tests/rasterise_tests.py:89,123-132: the same geometry (translation (0, 0, -1), rotation 0.5)
+    over a black and a blue background, random vertex colours per scene."""
+    a = cylinder_scene((0., 0., -1.), 0.5, seed=seed)
+    rng = np.random.default_rng(seed + 7)
+    V = a['vertices'].shape[0]
+    h, w = a['height'], a['width']
+    bg = np.tile(np.array([[0., 0., 0.], [0., 0., 1.]], np.float32)[:, None, None, :], [1, h, w, 1])
+    return dict(background=bg, vertices=np.tile(a['vertices'][None], [2, 1, 1]), faces=np.tile(a['faces'][None], [2, 1, 1]),
+                vertex_colors=rng.uniform(size=[2, V, 3]).astype(np.float32),
+                grad_pixels=rng.standard_normal([2, h, w, 3]).astype(np.float32), height=h, width=w, channels=3)
+
+
+def bent_square_geometry(translation=(0., 0., 0.), rotation=0.5, scale=(1., 1., 1.)):
+    """The bent square of the reference's tests/deferred_grad_test.py:18-55 (32 x 32 canvas): two faces split to six
+    vertices, rotated about z (rodrigues), scaled, translated, moved away from the camera and projected.  Returns
+    (vertices_clip [6,4], faces [2,3], vertices_world [6,4], vertex_colours [6,3]); the values are the reference's
+    initial variables (rotation 0.5 as in :176-180)."""
+    square_size = 4.
+    v = np.array([[-1, -1, 0.], [-1, 1, 0], [1, 1, 0], [1, -1, -1.3]], np.float64) * square_size / 2
+    f = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    v = v[f.reshape(-1)]
+    f = np.arange(6, dtype=np.int32).reshape(2, 3)
+    v = np.concatenate([v, np.ones([6, 1])], axis=1)
+    world = v @ _rodrigues([0., 0., rotation]) * np.concatenate([scale, [1.]]) + np.concatenate([translation, [0.]])
+    view = np.eye(4)
+    view[3, :3] = [-0.5, 0., -3.5]
+    clip = world @ view @ _perspective(0.1, 20., 0.1, 1.0)
+    colours = np.concatenate([np.ones([3, 3]) * [0.8, 0.5, 0.], np.ones([3, 3]) * [0.5, 0.8, 0.]], axis=0)
+    return clip.astype(np.float32), f, world.astype(np.float32), colours.astype(np.float32)

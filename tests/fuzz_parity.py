@@ -1,6 +1,6 @@
 """Randomised parity sweep on an MI355X box: random frame sizes, channel counts, meshes (split / shared / hostile),
 kernel tile shapes and flags; every case compares the HIP path with the CPU oracle (forward
-and visibility bit for bit, gradients within 1e-4 of the tensor scale).  Not collected by pytest (open-ended: runs for a time budget);
+and visibility bit for bit, gradients within 1e-4 of the tensor scale).  A fixed-seed slice of it runs under pytest (tests/test_gpu_configs.py); as a script it is open-ended (a time budget);
 usage: python tests/fuzz_parity.py [seconds] [seed] [hostile]   (`hostile`: mostly hostile geometry, larger frames)"""
 import os
 import sys
@@ -14,37 +14,37 @@ import oracle  # noqa: E402
 from dirt_amd import scenes, rasterise_ops as ops  # noqa: E402
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    hard = len(sys.argv) > 3 and sys.argv[3] == 'hostile'
+def run(budget=None, max_cases=None, seed=0, hard=False, max_dim=None):
+    """Random cases until `budget` seconds have passed or `max_cases` are done; returns the number of cases."""
+    rng = np.random.default_rng(seed)
     dev = torch.device('cuda', 0)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     t0, n = time.time(), 0
-    while time.time() - t0 < budget:
-        H, W = int(rng.integers(1, 700 if hard else 400)), int(rng.integers(1, 700 if hard else 400))
+    top = max_dim or (700 if hard else 400)
+    while (budget is None or time.time() - t0 < budget) and (max_cases is None or n < max_cases):
+        H, W = int(rng.integers(1, top)), int(rng.integers(1, top))
         C = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 10]))
         kind = rng.choice(['split', 'shared', 'hostile', 'tiny'], p=[0.1, 0.1, 0.7, 0.1] if hard else None)
-        seed = int(rng.integers(0, 1 << 30))
+        seed_ = int(rng.integers(0, 1 << 30))
         if kind == 'hostile':
-            s = scenes.hostile_scene(H, W, C, seed, int(rng.integers(10, 1500)))
+            s = scenes.hostile_scene(H, W, C, seed_, int(rng.integers(10, 1500)))
         elif kind == 'tiny':
-            s = scenes.rand_scene(int(rng.integers(1, 4000)), H, W, C, seed, 0.001, 0.02)
+            s = scenes.rand_scene(int(rng.integers(1, 4000)), H, W, C, seed_, 0.001, 0.02)
         else:
-            s = scenes.rand_scene(int(rng.integers(1, 3000)), H, W, C, seed, float(rng.uniform(0.005, 0.1)), float(rng.uniform(0.1, 0.8)), kind == 'shared')
+            s = scenes.rand_scene(int(rng.integers(1, 3000)), H, W, C, seed_, float(rng.uniform(0.005, 0.1)), float(rng.uniform(0.1, 0.8)), kind == 'shared')
         flags = int(rng.choice([0, 0x200, 0x400])) | int(rng.choice([0, 1]))
         b = {k: v[None] for k, v in s.items() if isinstance(v, np.ndarray)}
         if kind in ('split', 'shared') and rng.random() < 0.4:  # a batch of scenes of the same sizes
             B = int(rng.integers(2, 4))
             F = b['faces'].shape[1]
-            bs = scenes.batch_scene(F, H, W, C, [seed + i for i in range(B)], r_lo=0.01, r_hi=0.3, shared=(kind == 'shared'))
+            bs = scenes.batch_scene(F, H, W, C, [seed_ + i for i in range(B)], r_lo=0.01, r_hi=0.3, shared=(kind == 'shared'))
             b = {k: bs[k] for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
         want = oracle.forward(b['background'], b['vertices'], b['vertex_colors'], b['faces'])
         use_state = rng.random() < 0.5  # the autograd path: the forward keeps its state, the backward consumes it
         got = ops._op_rasterise(t(b['background']), t(b['vertices']), t(b['vertex_colors']), t(b['faces']), H, W, C, flags=flags & ~1,
                                 keep_state=use_state)
         got, state = got if use_state else (got, None)
-        tag = (kind, b['vertices'].shape[0], H, W, C, seed, hex(flags), use_state)
+        tag = (kind, b['vertices'].shape[0], H, W, C, seed_, hex(flags), use_state)
         assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), ('forward', tag)
         ow = oracle.backward(b['vertices'], b['faces'], want, b['grad_pixels'], flags=flags & 1)
         gb, gv, gvc, _ = ops._op_rasterise_grad(t(b['vertices']), t(b['faces']), t(want), t(b['grad_pixels']), H, W, C, flags=flags, state=state)
@@ -56,6 +56,13 @@ def main():
             err = float(np.abs(g_ - w_).max())
             assert err <= 1e-4 * scale, (name, err, scale, tag)
         n += 1
+    return n
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    t0 = time.time()
+    n = run(budget=budget, seed=int(sys.argv[2]) if len(sys.argv) > 2 else 0, hard=len(sys.argv) > 3 and sys.argv[3] == 'hostile')
     print('fuzz_parity: %d random cases agree with the oracle in %.0f s' % (n, time.time() - t0))
 
 

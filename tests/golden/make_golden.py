@@ -27,6 +27,9 @@ CASES = {
     'rand_c3_48x36': ('rand', 150, 36, 48, 3, [3], 0.05, 0.3, False),       # the frame of tests/rasterise_tests.py:55-56
     'rand_c4_batch2': ('rand', 300, 64, 80, 4, [11, 12], 0.03, 0.2, False),  # groups [0:3],[3:4], Q1 across scenes
     'shared_c1': ('rand', 400, 72, 56, 1, [13], 0.0, 0.0, True),
+    'cylinder_48x36': ('cylinder',),             # the scene of the reference's tests/rasterise_tests.py:50-99,115
+    'cylinder_batch2': ('cylinder_batch',),      # ... and its batch of two (:89,123-132)
+    'bent_square_gbuffer': ('bent_square',),     # the 7-channel G-buffer of tests/deferred_grad_test.py:121-142
 }
 
 
@@ -41,6 +44,22 @@ def make_inputs(case):
         s['background'] = np.random.default_rng(1).uniform(0, 1, s['background'].shape).astype(np.float32)
         s['grad_pixels'] = np.random.default_rng(2).standard_normal(s['background'].shape).astype(np.float32)
         return {k: s[k][None] for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
+    if kind == 'cylinder':
+        s = scenes.cylinder_scene()
+        return {k: s[k][None] for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
+    if kind == 'cylinder_batch':
+        s = scenes.cylinder_batch_scene()
+        return {k: s[k] for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
+    if kind == 'bent_square':
+        # vertex attributes of get_pixels_deferred_v2 (tests/deferred_grad_test.py:123-124): mask 1, colours 3, normals 3
+        clip, faces, world, colours = scenes.bent_square_geometry()
+        tri = world[:, :3].reshape(-1, 3, 3)
+        n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        n /= np.linalg.norm(n, axis=-1, keepdims=True)
+        attrs = np.concatenate([np.ones([6, 1]), colours, np.repeat(n, 3, axis=0)], axis=1).astype(np.float32)
+        g = np.random.default_rng(5).standard_normal([1, 32, 32, 7]).astype(np.float32)
+        return {'background': np.zeros([1, 32, 32, 7], np.float32), 'vertices': clip[None], 'vertex_colors': attrs[None],
+                'faces': faces[None], 'grad_pixels': g}
     _, F, H, W, C, seeds, rlo, rhi, shared = case
     b = scenes.batch_scene(F, H, W, C, seeds, r_lo=rlo, r_hi=rhi, shared=shared)
     return {k: b[k] for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}

@@ -114,7 +114,7 @@ def test_deferred_matches_manual_composition(gpu, oracle):
     want_a = oracle.backward(s['vertices'][None], s['faces'][None], gbuf, gt.grad.cpu().numpy()[None])
     def close(got, want, what):
         scale = max(1.0, float(np.abs(want).max()))
-        assert float(np.abs(got.cpu().numpy() - want).max()) <= 2e-4 * scale, what
+        assert float(np.abs(got.cpu().numpy() - want).max()) <= 1e-4 * scale, what
     close(v.grad, want_v['grad_vertices'][0], 'vertices')
     close(attrs.grad, want_a['grad_vertex_colors'][0], 'attributes')
     close(bg.grad, want_a['grad_background'][0], 'background')
@@ -151,7 +151,7 @@ def test_batch_deferred_shares_one_visibility_pass(gpu, oracle, shaded_channels)
 
     def close(got, want, what):
         scale = max(1.0, float(np.abs(want).max()))
-        assert float(np.abs(got.cpu().numpy() - want).max()) <= 2e-4 * scale, what
+        assert float(np.abs(got.cpu().numpy() - want).max()) <= 1e-4 * scale, what
     close(v.grad, want_v['grad_vertices'], 'vertices')
     close(attrs.grad, want_a['grad_vertex_colors'], 'attributes')
     close(bg.grad, want_a['grad_background'], 'background')
