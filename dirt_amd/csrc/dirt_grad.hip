@@ -199,7 +199,7 @@ __device__ __forceinline__ void st_off(void* base, uint32_t off, T v)
 template <int CSPEC, bool DEBUG>
 __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParams p)
 {
-    constexpr int NPLANES = CSPEC ? CSPEC : PC;
+    constexpr int NPLANES = CSPEC ? CSPEC : 3;
     __shared__ __align__(16) float s_pix[NPLANES][PR][PS];  // the pass's channels of `pixels`, edge clamped
     __shared__ __align__(16) float2 s_vw[PR][VS];           // {clip_w, face} of every pixel of the halo'd tile
     __shared__ __align__(16) float2 s_inbox[GTHREADS / 64][ICELLS];  // per wave: (fx, fy) sent to each pixel of its region + ring
@@ -258,16 +258,11 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
     float2* const inbox = &s_inbox[wave][0];
     const int my_cell = (ry + 1) * IS + 4 * sx + 2;   // the strip's first pixel in the inbox
 
-    // channels of a pass: whole channel groups (dirt/rasterise_ops.py:148-152) starting at c0 that fit in PC channels
+    // channels of a pass.  The channel-specialised kernels are one pass; any other channel count takes one channel GROUP
+    // (dirt/rasterise_ops.py:148-152: groups of 3 while >= 3 channels remain, then singles) per pass.
     auto pass_channels = [&](int c0) {
         if (CSPEC) return (int)CSPEC;
-        int nch = 0;
-        for (int c = c0; c < C && nch < PC;) {
-            const int G = (c + 3 <= C) ? 3 : 1;
-            if (nch + G > PC) break;
-            nch += G; c += G;
-        }
-        return nch;
+        return (c0 + 3 <= C) ? 3 : 1;
     };
 
     // ---- staging: loads of the pass's channels of the pixels tile (+halo), edge clamped (at(), :113-124).  Item i is
@@ -341,6 +336,132 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
     }
     zero_inbox();
 
+    // (fx, fy) sent to this strip's own pixels by themselves (see "position factors" below); with several passes (any
+    // channel count) they, and the inbox, accumulate over all passes and the position gradients are formed once
+    using std::integral_constant;
+    float fxy[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { fxy[j][0] = 0.f; fxy[j][1] = 0.f; }
+
+    // ---- the face loop.  The wave walks the distinct faces among its pixels (key[j], -1 = none) and, with POS, among
+    //      the ring cells it holds (lkey): per face every lane forms its masked partial sums -- POS: 3 vertices x
+    //      (x, y, w) from b_k * fpos; NCHV colour channels: 3 vertices x b_k * g -- the sums are reduced across the wave
+    //      (wave_reduce_scatter) and one atomic instruction adds the totals to the face's three vertices. ----
+    auto face_loop = [&](auto nchv_tag, auto pos_tag, const int c0, const auto& g, const int (&key)[4], const bool (&covered)[4],
+                         const float (&fpos)[4][3], const int (&lkey)[2], const float (&lb)[2][3], const float (&lf)[2][3]) {
+        constexpr int NCHV = decltype(nchv_tag)::value;
+        constexpr bool POS = decltype(pos_tag)::value;
+        constexpr int NP = POS ? 9 : 0;
+        constexpr int NV = NP + 3 * NCHV;           // values per face
+        constexpr int NR = NV <= 16 ? 16 : 24;      // ... padded to what the wave reduction takes
+        // this lane's role: it adds value role_v of the face (reduce_value_of_lane): v < NP: component v % 3 (x, y, w) of
+        // grad_vertices of vertex v / 3; else colour (v - NP) % NCHV of vertex (v - NP) / NCHV
+        const int role_v = reduce_value_of_lane<NR>(lane);
+        const bool role_valid = role_v >= 0 && role_v < NV;
+        const bool role_pos = role_v < NP;
+        const int role_k = role_pos ? role_v / 3 : (role_v - NP) / (NCHV ? NCHV : 1);
+        const int role_e = role_pos ? (role_v % 3 == 2 ? 3 : role_v % 3) : c0 + (role_v - NP) % (NCHV ? NCHV : 1);
+        float* const role_base = role_pos ? grad_vertices + role_e : grad_vertex_colors + role_e;
+        const uint32_t role_stride = role_pos ? 16u : pixel_bytes;
+        // pending pixels / ring cells as wave-wide masks (scalar registers)
+        unsigned long long pend[6];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pend[j] = __builtin_amdgcn_ballot_w64(covered[j]);
+        pend[4] = POS ? __builtin_amdgcn_ballot_w64(lkey[0] >= 0) : 0ull;
+        pend[5] = POS ? __builtin_amdgcn_ballot_w64(lkey[1] >= 0) : 0ull;
+        for (;;) {
+            int K;
+            if (pend[0]) K = __builtin_amdgcn_readlane(key[0], __ffsll((long long)pend[0]) - 1);
+            else if (pend[1]) K = __builtin_amdgcn_readlane(key[1], __ffsll((long long)pend[1]) - 1);
+            else if (pend[2]) K = __builtin_amdgcn_readlane(key[2], __ffsll((long long)pend[2]) - 1);
+            else if (pend[3]) K = __builtin_amdgcn_readlane(key[3], __ffsll((long long)pend[3]) - 1);
+            else if (POS && pend[4]) K = __builtin_amdgcn_readlane(lkey[0], __ffsll((long long)pend[4]) - 1);
+            else if (POS && pend[5]) K = __builtin_amdgcn_readlane(lkey[1], __ffsll((long long)pend[5]) - 1);
+            else break;
+            // the face's vertex indices (a wave-uniform address: requested now, needed after the reduction)
+            const int32_t* fk = faces + (size_t)(uint32_t)K * 3;
+            const int v0 = fk[0], v1 = fk[1], v2 = fk[2];
+            float acc[NR];
+#pragma unroll
+            for (int v = NV; v < NR; ++v) acc[v] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool m = key[j] == K;
+                pend[j] &= ~__builtin_amdgcn_ballot_w64(m);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float bm = m ? bk[j][k] : 0.f;
+                    if constexpr (POS) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) acc[3 * k + c] = j == 0 ? bm * fpos[j][c] : fmaf(bm, fpos[j][c], acc[3 * k + c]);
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < NCHV; ++ch)
+                        acc[NP + NCHV * k + ch] = j == 0 ? bm * g[j][ch] : fmaf(bm, g[j][ch], acc[NP + NCHV * k + ch]);
+                }
+            }
+            if constexpr (POS) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const bool m = lkey[e] == K;
+                    const unsigned long long mm = __builtin_amdgcn_ballot_w64(m);
+                    if (mm != 0ull) {
+                        pend[4 + e] &= ~mm;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float bm = m ? lb[e][k] : 0.f;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) acc[3 * k + c] = fmaf(bm, lf[e][c], acc[3 * k + c]);
+                        }
+                    }
+                }
+            }
+            GCOUNT(1, 1);
+            const float total = wave_reduce_scatter<NR>(acc, lane);
+            const int vsel = role_k == 0 ? v0 : (role_k == 1 ? v1 : v2);
+            if (role_valid && total != 0.f)
+                atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(role_base) + (size_t)((uint32_t)vsel * role_stride)), total);
+        }
+    };
+
+    // ---- position totals of the strip's pixels (own sums + what the neighbours sent through the inbox, and fw of the
+    //      totals) and the ring: what this wave's pixels sent to pixels of other waves (the row above / below the region,
+    //      the column left / right of the tile).  Those pixels' faces take it through the face loop, at most two ring
+    //      cells per lane: cells 0-33 the row above, 34-67 the row below, 68-75 / 76-83 the columns left / right. ----
+    auto gather_positions = [&](float (&fpos)[4][3], int (&lkey)[2], float (&lb)[2][3], float (&lf)[2][3]) {
+        const float4 i01 = *reinterpret_cast<const float4*>(inbox + my_cell), i23 = *reinterpret_cast<const float4*>(inbox + my_cell + 2);
+        fpos[0][0] = fxy[0][0] + i01.x; fpos[0][1] = fxy[0][1] + i01.y; fpos[1][0] = fxy[1][0] + i01.z; fpos[1][1] = fxy[1][1] + i01.w;
+        fpos[2][0] = fxy[2][0] + i23.x; fpos[2][1] = fxy[2][1] + i23.y; fpos[3][0] = fxy[3][0] + i23.z; fpos[3][1] = fxy[3][1] + i23.w;
+        const float ndc_y_own = ((float)(H - 1 - y) + 0.5f) * (2.f / height_f) - 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ndc_x = ((float)(xs + j) + 0.5f) * (2.f / width_f) - 1.f;
+            fpos[j][2] = -(fpos[j][0] * ndc_x + fpos[j][1] * ndc_y_own);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = lane + 64 * e;
+            const bool top = r < 34, bottom = r >= 34 && r < 68, left = r >= 68 && r < 76;
+            const int ty = top ? -1 : (bottom ? 8 : (left ? r - 68 : r - 76));
+            const int tx = top ? r - 1 : (bottom ? r - 35 : (left ? -1 : 32));
+            lkey[e] = -1;
+            lb[e][0] = 0.f; lb[e][1] = 0.f; lb[e][2] = 0.f; lf[e][0] = 0.f; lf[e][1] = 0.f; lf[e][2] = 0.f;
+            if (r < RING) {
+                const float2 v = inbox[(ty + 1) * IS + tx + 2];
+                if (v.x != 0.f || v.y != 0.f) {  // only pixels inside the frame are ever sent anything
+                    const int py = y0 + 8 * wave + ty, px = x0 + tx;
+                    lkey[e] = __float_as_int(s_vw[8 * wave + ty + 1][tx + 2].y);
+                    const float2 nb = ld_off<float2>(state_b, (uint32_t)((py - row0) * W + px) * 8u);
+                    lb[e][0] = nb.x; lb[e][1] = nb.y; lb[e][2] = (1.f - nb.x) - nb.y;
+                    const float ndc_x = ((float)px + 0.5f) * (2.f / width_f) - 1.f;
+                    const float ndc_y = ((float)(H - 1 - py) + 0.5f) * (2.f / height_f) - 1.f;
+                    lf[e][0] = v.x; lf[e][1] = v.y; lf[e][2] = -(v.x * ndc_x + v.y * ndc_y);
+                }
+            }
+        }
+        GCOUNT(0, __popcll(__builtin_amdgcn_ballot_w64(lkey[0] >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(lkey[1] >= 0)));
+    };
+
     // One pass = the channel groups that fit in PC channels, starting at channel c0.  A pass has one of four
     // shapes -- {3}, {3,1}, {1}, {1,1} (dirt/rasterise_ops.py:148-152 packs groups of 3 while >= 3 channels remain,
     // then singles) -- and the body is instantiated for each, so that its loops and branches over channels and
@@ -349,8 +470,6 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
         constexpr int NCH = decltype(nch_tag)::value;
         constexpr int G0 = decltype(g0_tag)::value;
         constexpr int NG = 1 + (NCH - G0);          // channel groups in the pass
-        constexpr int NV = 9 + 3 * NCH;             // values per face: 3 vertices x {x, y, w} + 3 vertices x NCH colours
-        constexpr int NR = NV <= 16 ? 16 : 24;      // ... padded to what the wave reduction takes
 
         if (c0 != 0) stage_load(c0, NCH, stage_v);
         // this strip's grad_pixels
@@ -490,7 +609,26 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
             key[j] = covered[j] ? f_own[j] : -1;
         }
 
-        // ---- background gradient (:143-147): grad_pixels where nothing is covered, zero elsewhere ----
+        // ---- background gradient (:143-147): grad_pixels where nothing is covered, zero elsewhere.  With several passes
+        //      the first one writes whole pixels (every channel), so that a pixel's bytes are written once, not a few
+        //      of them in every pass. ----
+        if (CSPEC == 0) {
+            if (c0 == 0) {
+                for (int j = 0; j < 4; ++j) {
+                    if (!in_px[j]) continue;
+                    const uint32_t off = (own_rel + (uint32_t)j) * pixel_bytes;
+                    if ((C & 3) == 0 && aligned16) {
+                        for (int c = 0; c < C; c += 4) {
+                            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (!covered[j]) v = ld_off<float4>(gpix_t, off + 4u * c);
+                            st_off<float4>(gbk_t, off + 4u * c, v);
+                        }
+                    } else {
+                        for (int c = 0; c < C; ++c) st_off<float>(gbk_t, off + 4u * c, covered[j] ? 0.f : ld_off<float>(gpix_t, off + 4u * c));
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!in_px[j]) continue;
@@ -529,9 +667,6 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
         //      clip_w -- perspective-correct barycentrics -- so no vertex gather is needed; one v_rcp_f32, 1 ulp; agrees to
         //      float rounding), everything taken at the pixel whose fragment is used.  (fx, fy) are summed per such
         //      TARGET pixel -- own pixels in registers, neighbours through the inbox -- and fw is formed once per pixel. ----
-        float fpos[4][3];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { fpos[j][0] = 0.f; fpos[j][1] = 0.f; }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
 #pragma unroll
@@ -554,8 +689,8 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
                 const bool contributes = dilated | covered[j];
                 const float fx = contributes ? (dLx[gi][j] * (.5f * width_f)) * rcp_w : 0.f;
                 const float fy = contributes ? (dLy[gi][j] * (.5f * height_f)) * rcp_w : 0.f;
-                fpos[j][0] += dilated ? 0.f : fx;
-                fpos[j][1] += dilated ? 0.f : fy;
+                fxy[j][0] += dilated ? 0.f : fx;
+                fxy[j][1] += dilated ? 0.f : fy;
                 if (dilated) {  // few lanes: ds_add_f32 into the neighbour's cell
                     const int step = horiz ? 1 : -IS;                            // +x, or up = the previous row
                     float* cell = reinterpret_cast<float*>(inbox + (my_cell + j + (fwd ? step : -step)));
@@ -565,133 +700,49 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
             }
         }
         GMARK();  // 5 dilation done
-        // what the neighbours sent to this strip, and fw of the totals
-        {
-            const float4 i01 = *reinterpret_cast<const float4*>(inbox + my_cell), i23 = *reinterpret_cast<const float4*>(inbox + my_cell + 2);
-            fpos[0][0] += i01.x; fpos[0][1] += i01.y; fpos[1][0] += i01.z; fpos[1][1] += i01.w;
-            fpos[2][0] += i23.x; fpos[2][1] += i23.y; fpos[3][0] += i23.z; fpos[3][1] += i23.w;
-        }
-        const float ndc_y_own = ((float)(H - 1 - y) + 0.5f) * (2.f / height_f) - 1.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float ndc_x = ((float)(xs + j) + 0.5f) * (2.f / width_f) - 1.f;
-            fpos[j][2] = -(fpos[j][0] * ndc_x + fpos[j][1] * ndc_y_own);
-        }
-        // ---- the ring: what this wave's pixels sent to pixels of other waves (the row above / below the region, the column
-        //      left / right of the tile).  Those pixels' faces take it through the face loop, at most two ring cells per
-        //      lane: cells 0-33 the row above, 34-67 the row below, 68-75 / 76-83 the columns left / right. ----
-        int lkey[2];
-        float lb[2][3], lf[2][3];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int r = lane + 64 * e;
-            const bool top = r < 34, bottom = r >= 34 && r < 68, left = r >= 68 && r < 76;
-            const int ty = top ? -1 : (bottom ? 8 : (left ? r - 68 : r - 76));
-            const int tx = top ? r - 1 : (bottom ? r - 35 : (left ? -1 : 32));
-            lkey[e] = -1;
-            lb[e][0] = 0.f; lb[e][1] = 0.f; lb[e][2] = 0.f; lf[e][0] = 0.f; lf[e][1] = 0.f; lf[e][2] = 0.f;
-            if (r < RING) {
-                const float2 v = inbox[(ty + 1) * IS + tx + 2];
-                if (v.x != 0.f || v.y != 0.f) {  // only pixels inside the frame are ever sent anything
-                    const int py = y0 + 8 * wave + ty, px = x0 + tx;
-                    lkey[e] = __float_as_int(s_vw[8 * wave + ty + 1][tx + 2].y);
-                    const float2 nb = ld_off<float2>(state_b, (uint32_t)((py - row0) * W + px) * 8u);
-                    lb[e][0] = nb.x; lb[e][1] = nb.y; lb[e][2] = (1.f - nb.x) - nb.y;
-                    const float ndc_x = ((float)px + 0.5f) * (2.f / width_f) - 1.f;
-                    const float ndc_y = ((float)(H - 1 - py) + 0.5f) * (2.f / height_f) - 1.f;
-                    lf[e][0] = v.x; lf[e][1] = v.y; lf[e][2] = -(v.x * ndc_x + v.y * ndc_y);
-                }
-            }
-        }
-        GCOUNT(0, __popcll(__builtin_amdgcn_ballot_w64(lkey[0] >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(lkey[1] >= 0)));
-
-        // ---- this lane's role in the face loop: it adds value role_v of the face (reduce_value_of_lane):
-        //      v < 9: component v % 3 (x, y, w) of grad_vertices of vertex v / 3; else colour (v - 9) % NCH of vertex
-        //      (v - 9) / NCH ----
-        const int role_v = reduce_value_of_lane<NR>(lane);
-        const bool role_valid = role_v >= 0 && role_v < NV;
-        const bool role_pos = role_v < 9;
-        const int role_k = role_pos ? role_v / 3 : (role_v - 9) / NCH;
-        const int role_e = role_pos ? (role_v % 3 == 2 ? 3 : role_v % 3) : c0 + (role_v - 9) % NCH;
-        float* const role_base = role_pos ? grad_vertices + role_e : grad_vertex_colors + role_e;
-        const uint32_t role_stride = role_pos ? 16u : pixel_bytes;
-
-        // ---- the face loop: pending pixels / ring cells as wave-wide masks (scalar registers) ----
-        unsigned long long pend[6];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pend[j] = __builtin_amdgcn_ballot_w64(covered[j]);
-        pend[4] = __builtin_amdgcn_ballot_w64(lkey[0] >= 0);
-        pend[5] = __builtin_amdgcn_ballot_w64(lkey[1] >= 0);
-        GMARK();  // 6 face loop starts
-        for (;;) {
-            int K;
-            if (pend[0]) K = __builtin_amdgcn_readlane(key[0], __ffsll((long long)pend[0]) - 1);
-            else if (pend[1]) K = __builtin_amdgcn_readlane(key[1], __ffsll((long long)pend[1]) - 1);
-            else if (pend[2]) K = __builtin_amdgcn_readlane(key[2], __ffsll((long long)pend[2]) - 1);
-            else if (pend[3]) K = __builtin_amdgcn_readlane(key[3], __ffsll((long long)pend[3]) - 1);
-            else if (pend[4]) K = __builtin_amdgcn_readlane(lkey[0], __ffsll((long long)pend[4]) - 1);
-            else if (pend[5]) K = __builtin_amdgcn_readlane(lkey[1], __ffsll((long long)pend[5]) - 1);
-            else break;
-            // the face's vertex indices (a wave-uniform address: requested now, needed after the reduction)
-            const int32_t* fk = faces + (size_t)(uint32_t)K * 3;
-            const int v0 = fk[0], v1 = fk[1], v2 = fk[2];
-            float acc[NR];
-#pragma unroll
-            for (int v = NV; v < NR; ++v) acc[v] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool m = key[j] == K;
-                pend[j] &= ~__builtin_amdgcn_ballot_w64(m);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float bm = m ? bk[j][k] : 0.f;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) acc[3 * k + c] = j == 0 ? bm * fpos[j][c] : fmaf(bm, fpos[j][c], acc[3 * k + c]);
-#pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch)
-                        acc[9 + NCH * k + ch] = j == 0 ? bm * g[j][ch] : fmaf(bm, g[j][ch], acc[9 + NCH * k + ch]);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const bool m = lkey[e] == K;
-                const unsigned long long mm = __builtin_amdgcn_ballot_w64(m);
-                if (mm != 0ull) {
-                    pend[4 + e] &= ~mm;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float bm = m ? lb[e][k] : 0.f;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) acc[3 * k + c] = fmaf(bm, lf[e][c], acc[3 * k + c]);
-                    }
-                }
-            }
-            GCOUNT(1, 1);
-            const float total = wave_reduce_scatter<NR>(acc, lane);
-            const int vsel = role_k == 0 ? v0 : (role_k == 1 ? v1 : v2);
-            if (role_valid && total != 0.f)
-                atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(role_base) + (size_t)((uint32_t)vsel * role_stride)), total);
+        if constexpr (CSPEC != 0) {   // one pass: positions and colours in one face loop
+            float fpos[4][3];
+            int lkey[2];
+            float lb[2][3], lf[2][3];
+            gather_positions(fpos, lkey, lb, lf);
+            GMARK();  // 6 face loop starts
+            face_loop(integral_constant<int, NCH>{}, integral_constant<bool, true>{}, c0, g, key, covered, fpos, lkey, lb, lf);
+        } else {                      // the pass's colour gradients now; the position gradients after the last pass
+            const float none3[4][3] = {};
+            const int nokey[2] = {-1, -1};
+            const float none2[2][3] = {};
+            face_loop(integral_constant<int, NCH>{}, integral_constant<bool, false>{}, c0, g, key, covered, none3, nokey, none2, none2);
         }
     };
 
-    using std::integral_constant;
     for (int c0 = 0; c0 < C;) {
         const int nch = pass_channels(c0);
         if constexpr (CSPEC != 0) {
             run_pass(integral_constant<int, CSPEC>{}, integral_constant<int, CSPEC == 1 ? 1 : 3>{}, 0);
-        } else if (c0 + 3 <= C) {
-            if (nch == 4) run_pass(integral_constant<int, 4>{}, integral_constant<int, 3>{}, c0);
-            else run_pass(integral_constant<int, 3>{}, integral_constant<int, 3>{}, c0);
+        } else if (nch == 3) {
+            run_pass(integral_constant<int, 3>{}, integral_constant<int, 3>{}, c0);
         } else {
-            if (nch == 2) run_pass(integral_constant<int, 2>{}, integral_constant<int, 1>{}, c0);
-            else run_pass(integral_constant<int, 1>{}, integral_constant<int, 1>{}, c0);
+            run_pass(integral_constant<int, 1>{}, integral_constant<int, 1>{}, c0);
         }
         c0 += nch;
         if (CSPEC) break;  // a single pass, statically
-        if (c0 < C) {
-            zero_inbox();     // this wave's own; nobody else touches it
-            __syncthreads();  // every wave is done with the planes
+        if (c0 < C) __syncthreads();  // every wave is done with the planes
+    }
+    if constexpr (CSPEC == 0) {   // the position gradients of all passes (fxy and the inbox accumulated over them)
+        int key[4];
+        bool covered[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = __float_as_int(s_vw[hr][4 * sx + 2 + j].y);
+            covered[j] = in_px[j] & (f >= 0);
+            key[j] = covered[j] ? f : -1;
         }
+        float fpos[4][3];
+        int lkey[2];
+        float lb[2][3], lf[2][3];
+        gather_positions(fpos, lkey, lb, lf);
+        const float nog[4][1] = {};
+        face_loop(integral_constant<int, 0>{}, integral_constant<bool, true>{}, 0, nog, key, covered, fpos, lkey, lb, lf);
     }
     GMARK();  // 7 done
 #ifdef DIRT_TRACE

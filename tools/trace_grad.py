@@ -43,11 +43,11 @@ cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; simd = (hw >> 4)
 blk = np.arange(len(a)) // 4
 key = se * 32 + sh * 16 + cu
 print('  placement (XCD 0 = blocks 0, 8, 16, ...): block -> (se, sh, cu) of its first wave')
-sel = [b for b in range(0, 8 * 140, 8)]
+sel = [b for b in range(0, min(8 * 140, len(a) // 4), 8)]
 print('   ', ' '.join('%d:%d.%d.%d' % (b, se[4 * b], sh[4 * b], cu[4 * b]) for b in sel[:48]))
 from collections import defaultdict
 g = defaultdict(list)
 for b in range(0, len(a) // 4, 8):
     g[int(key[4 * b])].append(b)
 print('    blocks sharing a CU on XCD 0:', [v for v in list(g.values())[:6]])
-print('    SIMD of the 4 waves of block 0 / 8 / 16:', simd[0:4], simd[32:36], simd[64:68])
+print('    SIMD of the 4 waves of block 0:', simd[0:4])
