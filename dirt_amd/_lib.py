@@ -19,6 +19,8 @@ FLAG_PROFILE = 0x100
 FLAG_TILES_LARGE = 0x200
 FLAG_TILES_SMALL = 0x400
 FLAG_SHARED_FACES = 0x800
+TEX_CLAMP = 1
+TEX_NEAREST = 2
 
 E_INVALID_ARGUMENT = -1
 E_TOO_MANY_VERTICES = -2
@@ -31,7 +33,8 @@ _lib = None
 SYMBOLS = ('dirt_abi_version', 'dirt_last_error', 'dirt_workspace_bytes', 'dirt_rasterise_forward',
            'dirt_rasterise_backward', 'dirt_rasterise_visibility', 'dirt_state_grad_buffers', 'dirt_profile_count',
            'dirt_profile_name',
-           'dirt_profile_read', 'dirt_profile_reset')
+           'dirt_profile_read', 'dirt_profile_reset', 'dirt_texture_sample_forward', 'dirt_texture_sample_backward',
+           'dirt_texture_last_error')
 
 
 class DirtLibraryError(RuntimeError):
@@ -71,6 +74,12 @@ def load():
     lib.dirt_profile_read.argtypes = [i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
     lib.dirt_profile_read.restype = i
     lib.dirt_profile_reset.restype = i
+    ll = ctypes.c_longlong
+    lib.dirt_texture_sample_forward.argtypes = [fp, fp, fp, ll, i, i, i, i, u, vp]
+    lib.dirt_texture_sample_forward.restype = i
+    lib.dirt_texture_sample_backward.argtypes = [fp, fp, fp, fp, fp, ll, i, i, i, i, i, u, vp]
+    lib.dirt_texture_sample_backward.restype = i
+    lib.dirt_texture_last_error.restype = ctypes.c_char_p
     if lib.dirt_abi_version() != ABI_VERSION:
         raise DirtLibraryError('libdirt_hip.so ABI %d != expected %d' % (lib.dirt_abi_version(), ABI_VERSION))
     _lib = lib

@@ -1,7 +1,13 @@
-"""Texture look-up for deferred shaders: the helpers of the reference's samples/textured.py:16-61 over torch
-tensors.  Gather-style dense math that runs after the rasteriser, inside `shader_fn`;
-differentiable with respect to the texture and (bilinear mode) the coordinates through torch autograd."""
+"""Texture look-up for deferred shaders: the helpers of the reference's samples/textured.py:16-61.
+
+`sample_texture_uv` is the fused path -- one HIP kernel for `sample_texture(texture, uvs_to_pixel_indices(uvs, shape,
+mode), filter)` and one for its gradient (include/dirt_hip.h: dirt_texture_sample_forward / _backward), reading the
+(u, v) pairs in place from a G-buffer slice.  `uvs_to_pixel_indices` and `sample_texture` are the reference's two
+functions over torch tensors (same names and arguments), kept for scripts that call them separately; both routes give
+the same values bit for bit."""
 import torch
+
+from . import _lib
 
 
 def uvs_to_pixel_indices(uvs, texture_shape, mode='repeat'):
@@ -37,3 +43,70 @@ def sample_texture(texture, indices, mode='bilinear'):
         return (fetch(r, c) * (1. - fc) * (1. - fr) + fetch(r, c + 1) * fc * (1. - fr)
                 + fetch(r + 1, c) * (1. - fc) * fr + fetch(r + 1, c + 1) * fc * fr)
     raise NotImplementedError(mode)
+
+
+def _pairs_in_place(uvs):
+    """(tensor to pass, element stride between pairs) such that pair i starts at data_ptr + 4 * i * stride: a slice
+    `gbuffer[..., a:a+2]` of a contiguous G-buffer is read in place, anything else is made contiguous."""
+    if uvs.stride(-1) == 1 and uvs.dim() >= 2:
+        step = uvs.stride(-2)
+        ok = step >= 2
+        expect = step
+        for d in range(uvs.dim() - 2, -1, -1):
+            if uvs.stride(d) != expect:
+                ok = False
+                break
+            expect *= uvs.shape[d]
+        if ok:
+            return uvs, step
+    return uvs.contiguous(), 2
+
+
+class _SampleTextureUV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, texture, uvs, flags):
+        lib = _lib.load()
+        if not (texture.is_cuda and uvs.is_cuda):
+            raise RuntimeError('dirt_amd.texture.sample_texture_uv runs on an MI355X only; there is no CPU fallback')
+        texture = texture.contiguous()
+        src, stride = _pairs_in_place(uvs)
+        n = uvs.numel() // 2
+        ht, wt, ct = (int(d) for d in texture.shape)
+        out = torch.empty(tuple(uvs.shape[:-1]) + (ct,), dtype=torch.float32, device=texture.device)
+        with torch.cuda.device(texture.device):
+            rc = lib.dirt_texture_sample_forward(texture.data_ptr(), src.data_ptr(), out.data_ptr(), n, ht, wt, ct, stride, flags,
+                                                 torch.cuda.current_stream(texture.device).cuda_stream)
+        if rc:
+            raise ValueError(lib.dirt_texture_last_error().decode())
+        ctx.save_for_backward(texture, src)
+        ctx.meta = (stride, flags, tuple(uvs.shape))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        texture, src = ctx.saved_tensors
+        stride, flags, uv_shape = ctx.meta
+        ht, wt, ct = (int(d) for d in texture.shape)
+        n = 1
+        for d in uv_shape[:-1]:
+            n *= int(d)
+        grad_out = grad_out.contiguous().to(torch.float32)
+        grad_texture = torch.empty_like(texture)
+        grad_uvs = torch.empty(uv_shape, dtype=torch.float32, device=texture.device) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(texture.device):
+            rc = lib.dirt_texture_sample_backward(texture.data_ptr(), src.data_ptr(), grad_out.data_ptr(), grad_texture.data_ptr(),
+                                                  grad_uvs.data_ptr() if grad_uvs is not None else None, n, ht, wt, ct, stride, 2, flags,
+                                                  torch.cuda.current_stream(texture.device).cuda_stream)
+        if rc:
+            raise ValueError(lib.dirt_texture_last_error().decode())
+        return grad_texture, grad_uvs, None
+
+
+def sample_texture_uv(texture, uvs, mode='repeat', filter='bilinear'):
+    """Fused `sample_texture(texture, uvs_to_pixel_indices(uvs, texture.shape[:2], mode), filter)`
+    (samples/textured.py:16-61, as its shader_fn uses them, :116-141): texture [Ht, Wt, C] float32, uvs [*, 2] with
+    (0, 0) at the top-left of the image -> [*, C].  Differentiable with respect to the texture and the coordinates."""
+    flags = {'repeat': 0, 'clamp': _lib.TEX_CLAMP}[mode] | {'bilinear': 0, 'nearest': _lib.TEX_NEAREST}[filter]
+    return _SampleTextureUV.apply(texture.to(torch.float32), uvs.to(torch.float32), flags)

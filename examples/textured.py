@@ -45,7 +45,7 @@ def checker_texture(size=128):
 
 def shader_fn(gbuffer, texture, light_direction):
     mask, uvs, normals = gbuffer[..., :1], gbuffer[..., 1:3], gbuffer[..., 3:]
-    unlit = tex.sample_texture(texture, tex.uvs_to_pixel_indices(uvs, texture.shape[:2]))
+    unlit = tex.sample_texture_uv(texture, uvs)  # one kernel: uvs_to_pixel_indices + bilinear sample_texture (samples/textured.py:16-61)
     ambient = unlit * 0.4
     diffuse = lighting.diffuse_directional(normals.reshape(-1, 3), unlit.reshape(-1, 3), light_direction,
                                            light_color=torch.full((3,), 0.6, device=gbuffer.device), double_sided=True)
@@ -53,7 +53,8 @@ def shader_fn(gbuffer, texture, light_direction):
     return (diffuse.reshape(unlit.shape) + ambient) * mask + background * (1. - mask)
 
 
-def render(vertices_object, uvs, faces, texture, light_direction):
+def geometry(vertices_object, uvs, faces):
+    """-> (clip-space vertices [V,4], vertex attributes [V,6] = mask, texture coordinates, normals)."""
     device = vertices_object.device
     v = torch.cat([vertices_object, torch.ones_like(vertices_object[:, -1:])], dim=1)
     world = v @ matrices.rodrigues(torch.tensor([0., 0.6, 0.], device=device))
@@ -61,10 +62,14 @@ def render(vertices_object, uvs, faces, texture, light_direction):
     view = matrices.compose(matrices.translation(torch.tensor([0., -2., -3.2], device=device)),
                             matrices.rodrigues(torch.tensor([-0.5, 0., 0.], device=device)))
     clip = (world @ view) @ matrices.perspective_projection(near=0.1, far=20., right=0.1, aspect=float(frame_height) / frame_width).to(device)
-    attributes = torch.cat([torch.ones_like(v[:, :1]), uvs, normals], dim=1)  # mask, texture coordinates, normals
+    return clip, torch.cat([torch.ones_like(v[:, :1]), uvs, normals], dim=1)
+
+
+def render(vertices_object, uvs, faces, texture, light_direction):
+    clip, attributes = geometry(vertices_object, uvs, faces)
     return dirt.rasterise_deferred(
         vertices=clip, vertex_attributes=attributes, faces=faces,
-        background_attributes=torch.zeros([frame_height, frame_width, 6], device=device),
+        background_attributes=torch.zeros([frame_height, frame_width, 6], device=clip.device),
         shader_fn=shader_fn, shader_additional_inputs=[texture, light_direction])
 
 

@@ -138,6 +138,28 @@ int dirt_state_grad_buffers(void *workspace, size_t workspace_bytes, int B, int 
                             float **grad_vertices, float **grad_vertex_colors);
 
 /*
+ * Texture look-up of a deferred shader, fused.  Replaces the TensorFlow composition
+ * `sample_texture(texture, uvs_to_pixel_indices(uvs, shape, mode), filter)` of the reference's samples/textured.py:16-61
+ * as used by its shader_fn (samples/textured.py:116-141): (u, v) with (0, 0) at the TOP-LEFT of the image -> repeat
+ * (uvs % 1) or clamp -> scaled by the texture size -> bilinear blend of the four neighbours (fraction of the index, no
+ * half-texel shift) or nearest.  Float32, the reference's operation order; where its gather would read row Ht / column Wt
+ * the last texel is used.
+ *   texture [Ht,Wt,Ct]; uvs: n pairs (u, v) `uv_stride` >= 2 floats apart -- read in place from a G-buffer [H,W,C] with
+ *   uv_stride = C and the pointer at the u channel; out [n,Ct].
+ * Backward: grad_out [n,Ct] -> grad_texture [Ht,Wt,Ct] (cleared by the call, then accumulated with float atomics) and
+ * grad_uvs (n pairs `grad_uv_stride` apart; may be NULL).
+ * dirt_texture_last_error(): thread-local description of the last failure of these two calls.
+ */
+#define DIRT_TEX_CLAMP 1u   /* mode 'clamp' instead of 'repeat' (samples/textured.py:21-24) */
+#define DIRT_TEX_NEAREST 2u /* mode 'nearest' instead of 'bilinear' (samples/textured.py:31-33) */
+int dirt_texture_sample_forward(const float *texture, const float *uvs, float *out, long long n, int Ht, int Wt, int Ct,
+                                int uv_stride, unsigned flags, void *stream);
+int dirt_texture_sample_backward(const float *texture, const float *uvs, const float *grad_out, float *grad_texture,
+                                 float *grad_uvs, long long n, int Ht, int Wt, int Ct, int uv_stride, int grad_uv_stride,
+                                 unsigned flags, void *stream);
+const char *dirt_texture_last_error(void);
+
+/*
  * Per-kernel timing (host-side state only).  Slots are the library's kernels; dirt_profile_count()
  * returns how many there are, dirt_profile_name(i) their names.  dirt_profile_read waits for the
  * recorded events of calls made with DIRT_FLAG_PROFILE on this thread, adds them to the running

@@ -152,7 +152,7 @@ def test_channel_groups_follow_the_reference():
     assert ref_groups(16) == [(0, 3), (3, 6), (6, 9), (9, 12), (12, 15), (15, 16)]
     assert ref_groups(5) == [(0, 3), (3, 4), (4, 5)]
     src = open(os.path.join(ROOT, 'dirt_amd', 'csrc', 'dirt_grad.hip')).read()
-    assert '(c + 3 <= C) ? 3 : 1' in src  # pass_channels: groups of 3 while >= 3 channels remain, then singles
+    assert '(c0 + 3 <= C) ? 3 : 1' in src  # pass_channels: groups of 3 while >= 3 channels remain, then singles
 
 
 def test_scene_generators_are_deterministic():

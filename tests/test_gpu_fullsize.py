@@ -215,23 +215,97 @@ def test_simple_sample_end_to_end(gpu, oracle):
     assert float(rotation.grad[1]) > 0  # turning back towards the target (smaller angle) lowers the loss
 
 
-def test_textured_sample_end_to_end(gpu):
-    """samples/textured.py on dirt_amd: deferred shading with a texture look-up; the loss reaches the texture,
-    the light direction and the vertices."""
+def _load_example(name):
     import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location('example_textured', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'textured.py'))
+    spec = importlib.util.spec_from_file_location('example_' + name, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', name + '.py'))
     ex = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ex)
+    return ex
+
+
+def _deferred_reference(oracle, clip, faces, attributes, n_channels, H, W, shade, d):
+    """Manual composition on the oracle (dirt/rasterise_ops.py:189-248): G-buffer by the oracle, shading and its autograd
+    by torch, vertex gradients from the SHADED image, attribute gradients from the G-buffer."""
+    gpu = clip.device
+    clip_np, faces_np, attr_np = clip.detach().cpu().numpy(), faces.cpu().numpy(), attributes.detach().cpu().numpy()
+    gbuf = oracle.forward(np.zeros((1, H, W, n_channels), np.float32), clip_np[None], attr_np[None], faces_np[None])
+    gt = torch.from_numpy(gbuf[0]).to(gpu).requires_grad_(True)
+    shaded = shade(gt)
+    shaded.backward(d)
+    want_v = oracle.backward(clip_np[None], faces_np[None], shaded.detach().cpu().numpy()[None], d.cpu().numpy()[None])
+    want_a = oracle.backward(clip_np[None], faces_np[None], gbuf, gt.grad.cpu().numpy()[None])
+    return shaded.detach(), want_v['grad_vertices'][0], want_a['grad_vertex_colors'][0]
+
+
+def _close(got, want, what, tol=1e-4):
+    want = want if isinstance(want, np.ndarray) else want.detach().cpu().numpy()
+    scale = max(1.0, float(np.abs(want).max()))
+    assert float(np.abs(got.detach().cpu().numpy() - want).max()) <= tol * scale, what
+
+
+def test_textured_sample_end_to_end(gpu, oracle):
+    """samples/textured.py on dirt_amd: deferred shading with the fused texture look-up.  The image, and the gradients
+    that reach the clip-space vertices, the vertex attributes, the texture and the light direction, against the manual
+    composition on the oracle with the UNFUSED torch helpers."""
+    from dirt_amd import texture as tex
+    ex = _load_example('textured')
     vertices, uvs, faces = (torch.from_numpy(a).to(gpu) for a in ex.build_cube())
     texture = torch.from_numpy(ex.checker_texture()).to(gpu).requires_grad_(True)
     light = torch.nn.functional.normalize(torch.tensor([1., -0.3, -0.5], device=gpu), dim=0).requires_grad_(True)
-    vertices.requires_grad_(True)
-    px = ex.render(vertices, uvs, faces, texture, light)
-    assert px.shape == (ex.frame_height, ex.frame_width, 3) and bool(torch.isfinite(px).all())
-    background = torch.tensor([0., 0., 0.3], device=gpu)
-    covered = (px - background).abs().sum(-1) > 1e-6
+    clip, attributes = ex.geometry(vertices, uvs, faces)
+    clip = clip.detach().requires_grad_(True)
+    attributes = attributes.detach().requires_grad_(True)
+    H, W = ex.frame_height, ex.frame_width
+    px = ops.rasterise_deferred(torch.zeros([H, W, 6], device=gpu), clip, attributes, faces, ex.shader_fn, [texture, light])
+    covered = (px - torch.tensor([0., 0., 0.3], device=gpu)).abs().sum(-1) > 1e-6
     assert 0.1 < float(covered.float().mean()) < 0.7
-    (px ** 2).mean().backward()
-    for t in (texture, light, vertices):
-        assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0
+    d = (2.0 / px.numel()) * px.detach()            # d/dpixels of mean(pixels ** 2)
+    px.backward(d)
+
+    tex2 = texture.detach().clone().requires_grad_(True)
+    light2 = light.detach().clone().requires_grad_(True)
+
+    def shade(gbuffer):   # the example's shader with the look-up spelled out as the reference does (samples/textured.py:120-141)
+        mask, uv, normals = gbuffer[..., :1], gbuffer[..., 1:3], gbuffer[..., 3:]
+        unlit = tex.sample_texture(tex2, tex.uvs_to_pixel_indices(uv, tex2.shape[:2]))
+        from dirt_amd import lighting
+        diffuse = lighting.diffuse_directional(normals.reshape(-1, 3), unlit.reshape(-1, 3), light2,
+                                               light_color=torch.full((3,), 0.6, device=gpu), double_sided=True)
+        return (diffuse.reshape(unlit.shape) + unlit * 0.4) * mask + torch.tensor([0., 0., 0.3], device=gpu) * (1. - mask)
+
+    shaded, want_v, want_a = _deferred_reference(oracle, clip, faces, attributes, 6, H, W, shade, d)
+    assert torch.allclose(px, shaded, atol=1e-6)
+    _close(clip.grad, want_v, 'clip-space vertices')
+    _close(attributes.grad, want_a, 'vertex attributes')
+    _close(texture.grad, tex2.grad, 'texture')
+    _close(light.grad, light2.grad, 'light direction', tol=1e-5)
+
+
+def test_deferred_sample_end_to_end(gpu, oracle):
+    """samples/deferred.py:58-117 on dirt_amd: the 10-channel G-buffer (mask, position, colour, normal) with per-pixel
+    ambient + diffuse + Phong specular lighting, the view matrix and the light direction as shader inputs."""
+    ex = _load_example('deferred')
+    from dirt_amd import matrices
+    vertices, faces = (torch.from_numpy(a).to(gpu) for a in ex.build_cube())
+    view = matrices.compose(matrices.translation(torch.tensor([0., -1.5, -3.5], device=gpu)),
+                            matrices.rodrigues(torch.tensor([-0.3, 0., 0.], device=gpu)))
+    light = torch.nn.functional.normalize(torch.tensor([1., -0.3, -0.5], device=gpu), dim=0)
+    clip, faces, attributes = ex.geometry(vertices, faces, view)
+    clip = clip.detach().requires_grad_(True)
+    attributes = attributes.detach().requires_grad_(True)
+    view_in = view.detach().clone().requires_grad_(True)
+    light_in = light.detach().clone().requires_grad_(True)
+    H, W = ex.frame_height, ex.frame_width
+    px = ops.rasterise_deferred(torch.zeros([H, W, 10], device=gpu), clip, attributes, faces, ex.shader_fn, [view_in, light_in])
+    assert 0.1 < float((px[..., 2] != 0.3).float().mean()) < 0.7
+    d = torch.from_numpy(np.random.default_rng(8).standard_normal((H, W, 3)).astype(np.float32)).to(gpu) / (H * W)
+    px.backward(d)
+    view2 = view.detach().clone().requires_grad_(True)
+    light2 = light.detach().clone().requires_grad_(True)
+    shaded, want_v, want_a = _deferred_reference(oracle, clip, faces, attributes, 10, H, W, lambda g: ex.shader_fn(g, view2, light2), d)
+    assert torch.allclose(px, shaded, atol=1e-6)
+    _close(clip.grad, want_v, 'clip-space vertices')
+    _close(attributes.grad, want_a, 'vertex attributes')
+    _close(view_in.grad, view2.grad, 'view matrix', tol=1e-5)
+    _close(light_in.grad, light2.grad, 'light direction', tol=1e-5)
