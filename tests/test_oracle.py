@@ -203,25 +203,43 @@ def test_degenerate_and_invalid_faces_are_skipped(oracle):
 
 # --------------------------------------------------------------------------------------------- backward
 
-def _numpy_assemble_grads(verts, faces, fid, bary, cw, pixels, g):
-    """Independent restatement of assemble_grads (csrc/rasterise_grad_egl.cu:93-236) for ONE scene and
-    ONE 3-channel group, vectorised numpy in float64, from the oracle's visibility arrays."""
-    H, W, _ = pixels.shape
+def _numpy_assemble_grads(verts, faces, fid, bary, cw, pixels, g, flat_group=None, iib=0, q1_intended=False):
+    """Independent restatement of assemble_grads (csrc/rasterise_grad_egl.cu:93-236) for ONE scene and ONE channel
+    group (pixels / g: [H,W,G], G = 3 or 1), vectorised numpy in float64, from the oracle's visibility arrays.
+
+    G = 1 reproduces quirk Q1 unless `q1_intended`: the L1 norms of :185 take "channels" 0, 1, 2 of a 1-channel
+    tensor, i.e. elements base, base + 1, base + 2 of the flattened [B,H,W,1] slice `flat_group` (this scene is number
+    `iib` in it), where base is the tap's (edge-clamped) pixel; past the end of the slice: its last element."""
+    H, W, G = pixels.shape
     V = verts.shape[0]
     pad = np.pad(pixels.astype(np.float64), ((1, 1), (1, 1), (0, 0)), mode='edge')
     at = lambda ox, oy: pad[1 - oy:H + 1 - oy, 1 + ox:W + 1 + ox]   # offset_y is UP in the image (GL y)
-    sx = (at(-1, -1) + at(-1, 1) - at(1, -1) - at(1, 1)) * (3 / 32) + (at(-1, 0) - at(1, 0)) * (10 / 32)
-    sy = (at(-1, -1) + at(1, -1) - at(-1, 1) - at(1, 1)) * (3 / 32) + (at(0, -1) - at(0, 1)) * (10 / 32)
+    scharr = lambda a: ((a(-1, -1) + a(-1, 1) - a(1, -1) - a(1, 1)) * (3 / 32) + (a(-1, 0) - a(1, 0)) * (10 / 32),
+                        (a(-1, -1) + a(1, -1) - a(-1, 1) - a(1, 1)) * (3 / 32) + (a(0, -1) - a(0, 1)) * (10 / 32))
+    sx, sy = scharr(at)
+    if G == 1 and not q1_intended:
+        flat = np.asarray(flat_group, np.float64).reshape(-1)
+        rr_, cc_ = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+
+        def at_alias(ch):
+            def a(ox, oy):
+                base = (iib * H + np.clip(rr_ - oy, 0, H - 1)) * W + np.clip(cc_ + ox, 0, W - 1)
+                return flat[np.minimum(base + ch, flat.size - 1)][..., None]
+            return a
+        l1x = sum(np.abs(scharr(at_alias(ch))[0][..., 0]) for ch in range(3))
+        l1y = sum(np.abs(scharr(at_alias(ch))[1][..., 0]) for ch in range(3))
+    else:
+        l1x, l1y = np.abs(sx).sum(-1), np.abs(sy).sum(-1)
     tri = np.where(fid[..., None] >= 0, faces[np.maximum(fid, 0)], -1)        # [H,W,3] vertex indices
     covered = fid >= 0
-    gv = np.zeros((V, 4)); gvc = np.zeros((V, 3)); gb = np.where(covered[..., None], 0, g).astype(np.float32)
+    gv = np.zeros((V, 4)); gvc = np.zeros((V, G)); gb = np.where(covered[..., None], 0, g).astype(np.float32)
     for k in range(3):
         np.add.at(gvc, tri[covered][:, k], (g[covered] * bary[covered][:, k:k + 1]).astype(np.float64))
     # dilation
     b2, t2, w2 = bary.copy(), tri.copy(), cw.copy()
     rr, cc = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
     interior = (cc > 0) & (rr > 0) & (cc < W - 1) & (rr < H - 1)
-    horiz = np.abs(sx).sum(-1) > np.abs(sy).sum(-1)
+    horiz = l1x > l1y
     ox = np.where(horiz, 1, 0); oy = np.where(horiz, 0, 1)
     flip = ((cc + rr) % 2) == 1
     ox = np.where(flip, -ox, ox); oy = np.where(flip, -oy, oy)
@@ -244,6 +262,68 @@ def _numpy_assemble_grads(verts, faces, fid, bary, cw, pixels, g):
             np.add.at(gv[:, 0], t2[cov2][:, k], gx[cov2]); np.add.at(gv[:, 1], t2[cov2][:, k], gy[cov2])
             np.add.at(gv[:, 3], t2[cov2][:, k], gw[cov2])
     return gb, gv, gvc, done
+
+
+def _numpy_backward_multichannel(oracle, b, px, q1_intended):
+    """`_rasterise_grad_multichannel` (dirt/rasterise_ops.py:132-177) on top of the numpy restatement: groups of 3 while
+    >= 3 channels remain, then singles (:148-152); grad_vertices summed over the groups (:163), the others concatenated."""
+    B, H, W, C = px.shape
+    V = b['vertices'].shape[1]
+    gb = np.zeros_like(px); gv = np.zeros((B, V, 4)); gvc = np.zeros((B, V, C))
+    vis = [oracle.visibility(b['vertices'][i], b['faces'][i], H, W) for i in range(B)]
+    c0 = 0
+    while c0 < C:
+        G = 3 if c0 + 3 <= C else 1
+        flat = np.ascontiguousarray(px[..., c0:c0 + G])          # what TF hands the op: the contiguous [B,H,W,G] slice
+        for i in range(B):
+            fid, bary, cw = vis[i]
+            a, v_, c_, _ = _numpy_assemble_grads(b['vertices'][i], b['faces'][i], fid, bary, cw, px[i, ..., c0:c0 + G],
+                                                 b['grad_pixels'][i, ..., c0:c0 + G], flat, i, q1_intended)
+            gb[i, ..., c0:c0 + G] = a; gv[i] += v_; gvc[i, :, c0:c0 + G] = c_
+        c0 += G
+    return gb, gv, gvc
+
+
+@pytest.mark.parametrize('C,seeds', [(1, [5]), (1, [6, 7]), (4, [8]), (5, [9, 10]), (7, [11])])
+@pytest.mark.parametrize('q1_intended', [False, True])
+def test_backward_groups_and_q1_match_numpy_restatement(oracle, C, seeds, q1_intended):
+    """The 1-channel group in both Q1 modes (aliased "channels" crossing pixel, row and SCENE boundaries in a batch) and
+    the multi-group sums of C = 4, 5, 7 against the independent numpy restatement -- the oracle is not compared with
+    itself here."""
+    b = scenes.batch_scene(120, 30, 44, C, seeds, r_lo=0.05, r_hi=0.3)
+    px = oracle.forward(b['background'], b['vertices'], b['vertex_colors'], b['faces'])
+    out = oracle.backward(b['vertices'], b['faces'], px, b['grad_pixels'], flags=1 if q1_intended else 0)
+    gb, gv, gvc = _numpy_backward_multichannel(oracle, b, px, q1_intended)
+    assert np.array_equal(out['grad_background'], gb)
+    assert np.allclose(out['grad_vertex_colors'], gvc, rtol=1e-5, atol=1e-5)
+    assert np.allclose(out['grad_vertices'], gv, rtol=1e-4, atol=1e-5 * np.abs(gv).max())
+
+
+def test_cylinder_translation_gradient_sanity_band(oracle):
+    """What the reference's tests/rasterise_tests.py:108-116 shows as images: the gradient of an image functional with
+    respect to the cylinder's translation.  dL/dvertices is a filter-based approximation (README.md:197), so central
+    finite differences over a couple of pixels are a sanity band: same sign, magnitude within a factor of two."""
+    h, w = 36, 48
+    ramp = np.linspace(-1, 1, w, dtype=np.float32)[None, :, None] * np.ones((h, 1, 3), np.float32)
+    bump = np.linspace(-1, 1, h, dtype=np.float32)[:, None, None] * np.ones((1, w, 3), np.float32)
+    P = scenes._perspective(0.1, 20., 0.2, float(h) / w)
+    for axis, g in ((0, ramp), (1, bump)):
+        def loss(t):
+            s = scenes.cylinder_scene(translation=t, bgcolor=(0.1, 0.1, 0.1), vertex_color=(0.9, 0.8, 0.7))
+            s['background'][:] = 0.1
+            s['vertex_colors'][:] = 0.9
+            px = oracle.forward(s['background'][None], s['vertices'][None], s['vertex_colors'][None], s['faces'][None])
+            return s, px, float((px[0].astype(np.float64) * g).sum())
+        t0 = [0., 0., -0.25]
+        s, px, _ = loss(t0)
+        out = oracle.backward(s['vertices'][None], s['faces'][None], px, g[None])
+        analytic = float((out['grad_vertices'][0].astype(np.float64) @ P[axis, :]).sum())   # d clip / d t_axis = row `axis` of P
+        step = 0.02                                                                      # ~2 pixels at this depth
+        tp, tm = list(t0), list(t0)
+        tp[axis] += step; tm[axis] -= step
+        fd = (loss(tp)[2] - loss(tm)[2]) / (2 * step)
+        assert fd * analytic > 0, (axis, fd, analytic)
+        assert 0.5 <= abs(analytic / fd) <= 2.0, (axis, fd, analytic)
 
 
 @pytest.mark.parametrize('seed,shared', [(3, False), (4, True)])
