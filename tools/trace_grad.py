@@ -51,3 +51,13 @@ for b in range(0, len(a) // 4, 8):
     g[int(key[4 * b])].append(b)
 print('    blocks sharing a CU on XCD 0:', [v for v in list(g.values())[:6]])
 print('    SIMD of the 4 waves of block 0:', simd[0:4])
+# how much of the spread of wave times is work (faces per region) and how much is placement
+it = a[:, 13].astype(np.float64)
+print('  corr(wave total, face-loop iterations) = %.2f;  totals: p50 %.0f p90 %.0f p99 %.0f max %.0f' % (
+    np.corrcoef(tot, it)[0, 1], *np.percentile(tot, [50, 90, 99, 100])))
+wg_it = it.reshape(-1, 4).sum(1); wg_end = tt[:, 7].reshape(-1, 4).max(1) - tt[:, 0].reshape(-1, 4).min(1)
+print('  per workgroup: corr(duration, iterations) = %.2f' % np.corrcoef(wg_end, wg_it)[0, 1])
+if len(wg_it) == 1024:
+    cu_it = wg_it.reshape(4, 256).sum(0); cu_end = wg_end.reshape(4, 256).max(0)
+    print('  per CU (blocks b, b+256, b+512, b+768): iterations mean %.0f max %.0f (+%.0f%%); slowest workgroup mean %.0f max %.0f; corr %.2f' % (
+        cu_it.mean(), cu_it.max(), 100 * (cu_it.max() / cu_it.mean() - 1), cu_end.mean(), cu_end.max(), np.corrcoef(cu_end, cu_it)[0, 1]))
