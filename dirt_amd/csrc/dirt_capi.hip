@@ -47,13 +47,19 @@ struct Scope {  // records an event pair around the launches issued during its l
     {
         if (!g_prof.pool.empty()) { hipEvent_t e = g_prof.pool.back(); g_prof.pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
-        (void)hipEventCreate(&e);
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         return e;
     }
     Scope(bool enabled, int slot, hipStream_t s) : on(enabled && g_prof.pending.size() < 65536), stream(s)
     {
         if (!on) return;
         p.slot = slot; p.a = get(); p.b = get();
+        if (!p.a || !p.b) {  // out of events: this launch goes untimed, the work itself is unaffected
+            if (p.a) g_prof.pool.push_back(p.a);
+            if (p.b) g_prof.pool.push_back(p.b);
+            on = false;
+            return;
+        }
         (void)hipEventRecord(p.a, stream);
     }
     ~Scope()

@@ -209,12 +209,6 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
     const long long tr_wall0 = wall_clock64();
 #endif
     GMARK();  // 0 start
-#ifdef DIRT_STAGGER
-    {   // experiment: offset the workgroups that share a CU in time, so that their memory and compute phases interleave
-        const int slot = DIRT_STAGGER_MAP;
-        for (int i = 0; i < slot * DIRT_STAGGER; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;

@@ -58,10 +58,10 @@ extern "C" {
                                     in separate outputs").  The state is caller-owned memory; the library
                                     stays stateless.  Results are identical with or without the flag. */
 
-#define DIRT_FLAG_TILES_LARGE 0x200u /* pin the kernels' tile shape instead of letting the library choose it from the
-                                       frame size and the face density (32x32 raster / 32x16 gradient tiles) ... */
-#define DIRT_FLAG_TILES_SMALL 0x400u /* ... or 16x16 / 32x8 tiles.  Results do not depend on the shape (pixels and
-                                       visibility bit for bit; gradients up to float-atomic order); for tests. */
+#define DIRT_FLAG_TILES_LARGE 0x200u /* pin the forward / visibility kernels' tile shape instead of letting the library
+                                       choose it from the frame size and the face density: 32x32 pixel tiles ... */
+#define DIRT_FLAG_TILES_SMALL 0x400u /* ... or 16x16.  Results do not depend on the shape (pixels and visibility bit for
+                                       bit); for tests.  The gradient kernel always works on 32x32 tiles. */
 #define DIRT_FLAG_SHARED_FACES 0x800u /* `faces` is one [F,3] topology shared by all B scenes instead of [B,F,3] (the
                                         TODO of csrc/rasterise_egl.cpp:314).  Same flag on the
                                         forward, visibility and backward calls of one scene batch. */

@@ -15,4 +15,13 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $RUN 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $RUN > /dev/null 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -o pmc -- $RUN > /dev/null 2>&1
 python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.log
+for cfg in K3-256 K3-2048 K5; do
+  python bench.py --config $cfg --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_$cfg.json 2>> $OUT/bench.log
+done
+python bench.py --scenes-per-gpu 8 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_K3x8.json 2>> $OUT/bench.log
+# the K5 gradient pass is the traffic-bound one: its own counters
+RUN5="python tools/prof_run.py K5 3"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_K5 -o trace -- $RUN5 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_K5 -o pmc -- $RUN5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_K5 -o pmc -- $RUN5 > /dev/null 2>&1
 ls -R $OUT | head -40

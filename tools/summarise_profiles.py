@@ -53,15 +53,28 @@ def main():
     open(os.path.join(dst, tag + '_pmc.txt'), 'w').write(buf.getvalue().replace(ROOT + '/', ''))
     line = [l for l in open(os.path.join(src, 'bench.json')).read().splitlines() if l.startswith('{')][-1]
     json.dump(json.loads(line), open(os.path.join(dst, tag + '_bench.json'), 'w'), indent=1)
-    fetch = counter(glob.glob(os.path.join(src, 'pmc_fetch', '*counter_collection.csv'))[0], 'FETCH_SIZE')
-    write = counter(glob.glob(os.path.join(src, 'pmc_write', '*counter_collection.csv'))[0], 'WRITE_SIZE')
-    traffic = {}
-    for k in fetch:
+    for extra in sorted(glob.glob(os.path.join(src, 'bench_*.json'))):
+        name = os.path.basename(extra)[len('bench_'):-len('.json')]
+        lines = [l for l in open(extra).read().splitlines() if l.startswith('{')]
+        if name != 'under_rocprof' and lines:
+            json.dump(json.loads(lines[-1]), open(os.path.join(dst, '%s_bench_%s.json' % (tag, name)), 'w'), indent=1)
+
+    def traffic_of(suffix):
+        fetch = counter(glob.glob(os.path.join(src, 'pmc_fetch' + suffix, '*counter_collection.csv'))[0], 'FETCH_SIZE')
+        write = counter(glob.glob(os.path.join(src, 'pmc_write' + suffix, '*counter_collection.csv'))[0], 'WRITE_SIZE')
         # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
-        traffic[slot(k)] = int(2 * fetch[k] * 1024 + write.get(k, 0) * 1024)
+        return {slot(k): int(2 * fetch[k] * 1024 + write.get(k, 0) * 1024) for k in fetch}
+
+    traffic = traffic_of('')
     path = os.path.join(dst, 'pmc_traffic.json')
     allt = json.load(open(path)) if os.path.exists(path) else {}
     allt[config] = traffic
+    allt['_collected'] = tag
+    if os.path.isdir(os.path.join(src, 'pmc_fetch_K5')):
+        allt['K5'] = traffic_of('_K5')
+        stats = os.path.join(src, 'trace_K5', 'trace_kernel_stats.csv')
+        if os.path.exists(stats):
+            shutil.copy(stats, os.path.join(dst, tag + '_kernel_stats_K5.csv'))
     allt['_note'] = ('HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes); the factor 2 is the gfx950 FETCH_SIZE '
                      'correction of MI355X_MICROARCH.md (calibrated there for wide coalesced reads; narrower accesses are uncalibrated)')
     json.dump(allt, open(path, 'w'), indent=1)
