@@ -194,12 +194,17 @@ __device__ __forceinline__ void st_off(void* base, uint32_t off, T v)
 }
 
 // grad_kernel<CSPEC>: CSPEC = 1, 3, 4: the channel count is that compile-time constant (4: with 16-byte aligned
-// pixel tensors) and the kernel is one pass; 0: any channel count, one pass per <= 4 channels of whole groups.
+// pixel tensors), one workgroup per tile.  0: any channel count: the channels are cut into PASSES of whole channel groups
+// (dirt/rasterise_ops.py:148-152) -- p.n3 passes of one 3-channel group, then (p.has4) one pass {3, 1}, then 1-channel
+// passes -- and a workgroup takes one (tile, pass): the same three bodies over `pixels` with a runtime channel stride.
+// The passes of a tile are consecutive work items of one XCD (xcd_tile), so they run at about the same time next to the
+// same L2: a pass uses 12 of the 64 bytes of a 16-channel pixel, and what one pass brings in from HBM the others find
+// there.  grad_vertices is summed over the groups by the atomics (dirt/rasterise_ops.py:167-171).
 // DEBUG: also write the reference's diagnostic output debug_thingy.
 template <int CSPEC, bool DEBUG>
-__global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParams p)
+__global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 {
-    constexpr int NPLANES = CSPEC ? CSPEC : 3;
+    constexpr int NPLANES = CSPEC ? CSPEC : 4;
     __shared__ __align__(16) float s_pix[NPLANES][PR][PS];  // the pass's channels of `pixels`, edge clamped
     __shared__ __align__(16) float2 s_vw[PR][VS];           // {clip_w, face} of every pixel of the halo'd tile
     __shared__ __align__(16) float2 s_inbox[GTHREADS / 64][ICELLS];  // per wave: (fx, fy) sent to each pixel of its region + ring
@@ -214,9 +219,20 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
     const int wave = tid >> 6;
     const int iib = blockIdx.y;
     const int H = p.H, W = p.W, C = CSPEC ? CSPEC : p.C;
-    const bool aligned16 = CSPEC == 4 ? true : (p.pixels_aligned16 != 0);
     const size_t frame = (size_t)H * W;
-    const int tile = xcd_tile((int)blockIdx.x, p.tiles_x * p.tiles_y);
+    // this workgroup's tile and pass: `shape` channels starting at channel cbase
+    int tile, shape = CSPEC, cbase = 0;
+    if constexpr (CSPEC != 0) {
+        tile = xcd_tile((int)blockIdx.x, p.tiles_x * p.tiles_y);
+    } else {
+        const int item = xcd_tile((int)blockIdx.x, p.tiles_x * p.tiles_y * p.npasses);
+        tile = item / p.npasses;
+        const int pass = item - tile * p.npasses;
+        if (pass < p.n3) { shape = 3; cbase = 3 * pass; }
+        else if (p.has4 && pass == p.n3) { shape = 4; cbase = 3 * p.n3; }
+        else { shape = 1; cbase = 3 * p.n3 + 4 * p.has4 + (pass - p.n3 - p.has4); }
+    }
+    const bool aligned16 = CSPEC == 4 ? true : (p.pixels_aligned16 != 0 && (cbase & 3) == 0);
     const int x0 = (tile % p.tiles_x) * GT, y0 = (tile / p.tiles_x) * GT;
 
     // Wave-uniform bases at the first staged row of the tile (row0), so that every per-lane address is a small
@@ -225,12 +241,12 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
     const size_t origin = (size_t)iib * frame + (size_t)row0 * W;   // pixel index of (row0, column 0)
     const float2* __restrict__ state_a = p.state_a + origin;         // {clip_w, face}
     const float2* __restrict__ state_b = p.state_b + origin;         // {b0, b1}
-    const float* __restrict__ pixels_t = p.pixels + origin * C;
-    const float* __restrict__ gpix_t = p.grad_pixels + origin * C;
-    float* __restrict__ gbk_t = p.grad_background + origin * C;
+    const float* __restrict__ pixels_t = p.pixels + origin * C + cbase;   // channel 0 of the pass
+    const float* __restrict__ gpix_t = p.grad_pixels + origin * C + cbase;
+    float* __restrict__ gbk_t = p.grad_background + origin * C + cbase;
     const int32_t* __restrict__ faces = p.faces + (p.shared_faces ? (size_t)0 : (size_t)iib * p.F * 3);
     float* __restrict__ grad_vertices = p.grad_vertices + (size_t)iib * p.V * 4;
-    float* __restrict__ grad_vertex_colors = p.grad_vertex_colors + (size_t)iib * p.V * C;
+    float* __restrict__ grad_vertex_colors = p.grad_vertex_colors + (size_t)iib * p.V * C + cbase;
     const uint32_t pixel_bytes = 4u * (uint32_t)C;
 
     const bool q1_intended = (p.flags & DIRT_FLAG_Q1_INTENDED) != 0;
@@ -252,25 +268,18 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
     float2* const inbox = &s_inbox[wave][0];
     const int my_cell = (ry + 1) * IS + 4 * sx + 2;   // the strip's first pixel in the inbox
 
-    // channels of a pass.  The channel-specialised kernels are one pass; any other channel count takes one channel GROUP
-    // (dirt/rasterise_ops.py:148-152: groups of 3 while >= 3 channels remain, then singles) per pass.
-    auto pass_channels = [&](int c0) {
-        if (CSPEC) return (int)CSPEC;
-        return (c0 + 3 <= C) ? 3 : 1;
-    };
-
     // ---- staging: loads of the pass's channels of the pixels tile (+halo), edge clamped (at(), :113-124).  Item i is
     //      row i / 36, column x0 - 1 + i % 36; five items per thread, every load issued before any use ----
     constexpr int PITEMS = (PR * PS + GTHREADS - 1) / GTHREADS;
-    auto stage_load = [&](int c0, int nch, float (&v)[PITEMS][PC]) {
+    auto stage_load = [&](int nch, float (&v)[PITEMS][PC]) {
 #pragma unroll
         for (int k = 0; k < PITEMS; ++k) {
             const int i = min(tid + k * GTHREADS, PR * PS - 1);
             const int row = i / PS, ci = i - row * PS;
             const int cy = min(max(y0 - 1 + row, 0), H - 1), cx = min(max(x0 - 1 + ci, 0), W - 1);
-            const uint32_t off = (uint32_t)((cy - row0) * W + cx) * pixel_bytes + 4u * (uint32_t)c0;
+            const uint32_t off = (uint32_t)((cy - row0) * W + cx) * pixel_bytes;
             if (nch == 4 && (C & 3) == 0 && aligned16) {
-                const float4 q = ld_off<float4>(pixels_t, off);  // c0 is a multiple of 4 here
+                const float4 q = ld_off<float4>(pixels_t, off);
                 v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
             } else {
 #pragma unroll
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
     //      Halo positions outside the frame are clamped; they are only ever consulted for interior pixels, whose
     //      neighbours are inside the frame. ----
     float stage_v[PITEMS][PC];
-    stage_load(0, pass_channels(0), stage_v);
+    stage_load(shape, stage_v);
     {
         constexpr int VITEMS = (PR * PR + GTHREADS - 1) / GTHREADS;
         float2 rec[VITEMS];
@@ -330,8 +339,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
     }
     zero_inbox();
 
-    // (fx, fy) sent to this strip's own pixels by themselves (see "position factors" below); with several passes (any
-    // channel count) they, and the inbox, accumulate over all passes and the position gradients are formed once
+    // (fx, fy) sent to this strip's own pixels by themselves (see "position factors" below)
     using std::integral_constant;
     float fxy[4][2];
 #pragma unroll
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
     //      the ring cells it holds (lkey): per face every lane forms its masked partial sums -- POS: 3 vertices x
     //      (x, y, w) from b_k * fpos; NCHV colour channels: 3 vertices x b_k * g -- the sums are reduced across the wave
     //      (wave_reduce_scatter) and one atomic instruction adds the totals to the face's three vertices. ----
-    auto face_loop = [&](auto nchv_tag, auto pos_tag, const int c0, const auto& g, const int (&key)[4], const bool (&covered)[4],
+    auto face_loop = [&](auto nchv_tag, auto pos_tag, const auto& g, const int (&key)[4], const bool (&covered)[4],
                          const float (&fpos)[4][3], const int (&lkey)[2], const float (&lb)[2][3], const float (&lf)[2][3]) {
         constexpr int NCHV = decltype(nchv_tag)::value;
         constexpr bool POS = decltype(pos_tag)::value;
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
         const bool role_valid = role_v >= 0 && role_v < NV;
         const bool role_pos = role_v < NP;
         const int role_k = role_pos ? role_v / 3 : (role_v - NP) / (NCHV ? NCHV : 1);
-        const int role_e = role_pos ? (role_v % 3 == 2 ? 3 : role_v % 3) : c0 + (role_v - NP) % (NCHV ? NCHV : 1);
+        const int role_e = role_pos ? (role_v % 3 == 2 ? 3 : role_v % 3) : (role_v - NP) % (NCHV ? NCHV : 1);
         float* const role_base = role_pos ? grad_vertices + role_e : grad_vertex_colors + role_e;
         const uint32_t role_stride = role_pos ? 16u : pixel_bytes;
         // pending pixels / ring cells as wave-wide masks (scalar registers)
@@ -456,22 +464,20 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
         GCOUNT(0, __popcll(__builtin_amdgcn_ballot_w64(lkey[0] >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(lkey[1] >= 0)));
     };
 
-    // One pass = the channel groups that fit in PC channels, starting at channel c0.  A pass has one of four
-    // shapes -- {3}, {3,1}, {1}, {1,1} (dirt/rasterise_ops.py:148-152 packs groups of 3 while >= 3 channels remain,
-    // then singles) -- and the body is instantiated for each, so that its loops and branches over channels and
-    // groups are static: NCH channels, the first group of size G0, every further group a single channel.
-    auto run_pass = [&](auto nch_tag, auto g0_tag, const int c0) {
+    // One pass = whole channel groups (dirt/rasterise_ops.py:148-152 packs groups of 3 while >= 3 channels remain, then
+    // singles) of one of three shapes -- {3}, {3,1}, {1} -- and the body is instantiated for each, so that its loops and
+    // branches over channels and groups are static: NCH channels, the first group of size G0, a further one a single.
+    auto run_pass = [&](auto nch_tag, auto g0_tag) {
         constexpr int NCH = decltype(nch_tag)::value;
         constexpr int G0 = decltype(g0_tag)::value;
         constexpr int NG = 1 + (NCH - G0);          // channel groups in the pass
 
-        if (c0 != 0) stage_load(c0, NCH, stage_v);
         // this strip's grad_pixels
-        const uint32_t own_off = own_rel * pixel_bytes + 4u * (uint32_t)c0;
+        const uint32_t own_off = own_rel * pixel_bytes;
         float g[4][NCH];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t off = in_px[j] ? own_off + (uint32_t)j * pixel_bytes : 4u * (uint32_t)c0;  // outside the frame: any valid address
+            const uint32_t off = in_px[j] ? own_off + (uint32_t)j * pixel_bytes : 0u;  // outside the frame: any valid address
             bool wide = false;
             if constexpr (NCH == 4) {
                 if ((C & 3) == 0 && aligned16) {
@@ -569,7 +575,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ib |= (interior[j] && xs + j + 3 > W - 1) ? (1u << j) : 0u;
                         if (__builtin_amdgcn_ballot_w64(ib != 0u) != 0ull)
-                            horiz_bits = alias_wrap_fixup(p.pixels, p.B, H, W, C, iib, y, xs, c0 + ch, ib, horiz_bits, 4 * gi);
+                            horiz_bits = alias_wrap_fixup(p.pixels, p.B, H, W, C, iib, y, xs, cbase + ch, ib, horiz_bits, 4 * gi);
                     }
                     asm volatile("" : "+v"(horiz_bits));  // decided here: the norms' registers are free again
                 }
@@ -603,26 +609,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
             key[j] = covered[j] ? f_own[j] : -1;
         }
 
-        // ---- background gradient (:143-147): grad_pixels where nothing is covered, zero elsewhere.  With several passes
-        //      the first one writes whole pixels (every channel), so that a pixel's bytes are written once, not a few
-        //      of them in every pass. ----
-        if (CSPEC == 0) {
-            if (c0 == 0) {
-                for (int j = 0; j < 4; ++j) {
-                    if (!in_px[j]) continue;
-                    const uint32_t off = (own_rel + (uint32_t)j) * pixel_bytes;
-                    if ((C & 3) == 0 && aligned16) {
-                        for (int c = 0; c < C; c += 4) {
-                            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (!covered[j]) v = ld_off<float4>(gpix_t, off + 4u * c);
-                            st_off<float4>(gbk_t, off + 4u * c, v);
-                        }
-                    } else {
-                        for (int c = 0; c < C; ++c) st_off<float>(gbk_t, off + 4u * c, covered[j] ? 0.f : ld_off<float>(gpix_t, off + 4u * c));
-                    }
-                }
-            }
-        } else
+        // ---- background gradient (:143-147): grad_pixels where nothing is covered, zero elsewhere ----
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!in_px[j]) continue;
@@ -677,7 +664,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
                 const float w_v = fwd ? w_up[j] : w_dn[j];
                 const float clip_w = dilated ? (horiz ? w_h : w_v) : w_own[j];
                 if constexpr (DEBUG) {
-                    if (c0 == 0 && gi == 0 && in_px[j]) write_debug(p.debug_thingy, p.grad_pixels, p.B, H, W, C, iib, y, xs + j, G0, dilated);
+                    if (cbase == 0 && gi == 0 && in_px[j]) write_debug(p.debug_thingy, p.grad_pixels, p.B, H, W, C, iib, y, xs + j, G0, dilated);
                 }
                 const float rcp_w = __builtin_amdgcn_rcpf(clip_w);
                 const bool contributes = dilated | covered[j];
@@ -694,50 +681,19 @@ __global__ __launch_bounds__(GTHREADS, CSPEC ? 4 : 3) void grad_kernel(GradParam
             }
         }
         GMARK();  // 5 dilation done
-        if constexpr (CSPEC != 0) {   // one pass: positions and colours in one face loop
-            float fpos[4][3];
-            int lkey[2];
-            float lb[2][3], lf[2][3];
-            gather_positions(fpos, lkey, lb, lf);
-            GMARK();  // 6 face loop starts
-            face_loop(integral_constant<int, NCH>{}, integral_constant<bool, true>{}, c0, g, key, covered, fpos, lkey, lb, lf);
-        } else {                      // the pass's colour gradients now; the position gradients after the last pass
-            const float none3[4][3] = {};
-            const int nokey[2] = {-1, -1};
-            const float none2[2][3] = {};
-            face_loop(integral_constant<int, NCH>{}, integral_constant<bool, false>{}, c0, g, key, covered, none3, nokey, none2, none2);
-        }
-    };
-
-    for (int c0 = 0; c0 < C;) {
-        const int nch = pass_channels(c0);
-        if constexpr (CSPEC != 0) {
-            run_pass(integral_constant<int, CSPEC>{}, integral_constant<int, CSPEC == 1 ? 1 : 3>{}, 0);
-        } else if (nch == 3) {
-            run_pass(integral_constant<int, 3>{}, integral_constant<int, 3>{}, c0);
-        } else {
-            run_pass(integral_constant<int, 1>{}, integral_constant<int, 1>{}, c0);
-        }
-        c0 += nch;
-        if (CSPEC) break;  // a single pass, statically
-        if (c0 < C) __syncthreads();  // every wave is done with the planes
-    }
-    if constexpr (CSPEC == 0) {   // the position gradients of all passes (fxy and the inbox accumulated over them)
-        int key[4];
-        bool covered[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = __float_as_int(s_vw[hr][4 * sx + 2 + j].y);
-            covered[j] = in_px[j] & (f >= 0);
-            key[j] = covered[j] ? f : -1;
-        }
+        // positions and colours in one face loop
         float fpos[4][3];
         int lkey[2];
         float lb[2][3], lf[2][3];
         gather_positions(fpos, lkey, lb, lf);
-        const float nog[4][1] = {};
-        face_loop(integral_constant<int, 0>{}, integral_constant<bool, true>{}, 0, nog, key, covered, fpos, lkey, lb, lf);
-    }
+        GMARK();  // 6 face loop starts
+        face_loop(integral_constant<int, NCH>{}, integral_constant<bool, true>{}, g, key, covered, fpos, lkey, lb, lf);
+    };
+
+    if constexpr (CSPEC != 0) run_pass(integral_constant<int, CSPEC>{}, integral_constant<int, CSPEC == 1 ? 1 : 3>{});
+    else if (shape == 3) run_pass(integral_constant<int, 3>{}, integral_constant<int, 3>{});
+    else if (shape == 4) run_pass(integral_constant<int, 4>{}, integral_constant<int, 3>{});
+    else run_pass(integral_constant<int, 1>{}, integral_constant<int, 1>{});
     GMARK();  // 7 done
 #ifdef DIRT_TRACE
     if (lane == 0 && g_trace_grad) {
@@ -759,7 +715,13 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
                            reinterpret_cast<uintptr_t>(p.grad_background)) & 15u) == 0 ? 1 : 0;
     // the common channel counts get kernels in which the pass / channel-group structure is static
     const int cspec = (p.C == 4 && p.pixels_aligned16) ? 4 : (p.C == 3 ? 3 : (p.C == 1 ? 1 : 0));
-    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)p.B), block(GTHREADS);
+    // any other channel count: passes of whole channel groups (groups of 3 while >= 3 channels remain, then singles,
+    // dirt/rasterise_ops.py:148-152); the last 3-group and the first single share a pass
+    const int groups3 = p.C / 3, singles = p.C % 3;
+    p.has4 = (groups3 >= 1 && singles >= 1) ? 1 : 0;
+    p.n3 = groups3 - p.has4;
+    p.npasses = cspec ? 1 : p.n3 + p.has4 + (singles - p.has4);
+    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.npasses), (unsigned)p.B), block(GTHREADS);
 #define DIRT_LAUNCH_GRAD(DBG_)                                                                          \
     do {                                                                                               \
         if (cspec == 4) hipLaunchKernelGGL((grad_kernel<4, DBG_>), grid, block, 0, stream, p);         \

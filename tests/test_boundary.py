@@ -152,7 +152,8 @@ def test_channel_groups_follow_the_reference():
     assert ref_groups(16) == [(0, 3), (3, 6), (6, 9), (9, 12), (12, 15), (15, 16)]
     assert ref_groups(5) == [(0, 3), (3, 4), (4, 5)]
     src = open(os.path.join(ROOT, 'dirt_amd', 'csrc', 'dirt_grad.hip')).read()
-    assert '(c0 + 3 <= C) ? 3 : 1' in src  # pass_channels: groups of 3 while >= 3 channels remain, then singles
+    # launch_grad: groups of 3 while >= 3 channels remain, then singles (the last 3-group and the first single share a pass)
+    assert 'const int groups3 = p.C / 3, singles = p.C % 3;' in src
 
 
 def test_scene_generators_are_deterministic():
