@@ -206,7 +206,9 @@ def main():
                 pj = json.load(open(pmc))
                 traffic = pj.get(args.config, {}).get(dom)
                 if traffic is not None:
-                    traffic_source = 'profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run' % pj.get('_collected', 'committed')
+                    traffic *= spg   # counted on one scene per launch; a launch of this run renders `spg` independent scenes
+                    traffic_source = ('profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of one scene of this workload'
+                                      '%s, not measured in this run' % (pj.get('_collected', 'committed'), ' x %d scenes per launch' % spg if spg > 1 else ''))
             except Exception:
                 traffic = None
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
