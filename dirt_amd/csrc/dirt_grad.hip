@@ -30,6 +30,7 @@
 #include "dirt_launch.h"
 #include "../../include/dirt_hip.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace dirt {
 
@@ -47,6 +48,32 @@ extern "C" void dirt_debug_set_trace_grad(void* p)
 #define GMARK() do {} while (0)
 #define GCOUNT(i, v) do {} while (0)
 #endif
+
+typedef unsigned long long lanemask;   // one bit per lane of the wave, wave-uniform (a scalar register pair)
+typedef float float2v __attribute__((ext_vector_type(2)));   // a register pair for the packed fp32 instructions (v_pk_fma_f32)
+
+// (s, s) * b [+ c] in one packed instruction.  op_sel_hi:[0,1,1] makes both halves take their first factor from the LOW
+// register of the first operand's pair, so the scalar needs no copy into a second register (the compiler, given a
+// splat, emits a v_mov per use); the pair's high register is never read.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+__device__ __forceinline__ float2v pk_fma_scalar(float s, float2v b, float2v c)
+{
+    float2v a;
+    a.x = s;
+    float2v d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float2v pk_mul_scalar(float s, float2v b)
+{
+    float2v a;
+    a.x = s;
+    float2v d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+#pragma clang diagnostic pop
 
 constexpr int GT = 32;                  // tile side (pixels)
 constexpr int GTHREADS = 256;           // 4 waves: wave w owns rows 8w .. 8w+7, lane l the strip x = 4 * (l & 7) .. +3 of row l >> 3
@@ -81,17 +108,35 @@ __device__ __forceinline__ float pack_pair(float lo, float hi, bool upper)
     return keep + dpp_mov<CTRL>(send);
 }
 
+// The same for the two levels whose "upper" lanes are whole DPP banks (lanes 8-15 of a row: banks 2, 3; lanes 4-7 and
+// 12-15: banks 1, 3): lo + partner's lo everywhere, then hi + partner's hi written to the upper banks only -- two
+// instructions, no selects.  (Written as assembly: the bank-masked form of a DPP add has no builtin.  A DPP operand
+// written by the preceding VALU instruction needs two wait states: the leading s_nop.)
+#define DIRT_PACK_PAIR_BANKED(NAME, CTRL_TEXT, UPPER_BANKS)                                                              \
+    __device__ __forceinline__ float NAME(float lo, float hi)                                                            \
+    {                                                                                                                   \
+        float r;                                                                                                        \
+        asm("s_nop 1\n\t"                                                                                               \
+            "v_add_f32_dpp %0, %1, %1 " CTRL_TEXT " row_mask:0xf bank_mask:0xf\n\t"                                      \
+            "v_add_f32_dpp %0, %2, %2 " CTRL_TEXT " row_mask:0xf bank_mask:" UPPER_BANKS                                 \
+            : "=&v"(r) : "v"(lo), "v"(hi));                                                                             \
+        return r;                                                                                                       \
+    }
+DIRT_PACK_PAIR_BANKED(pack_pair_row_mirror, "row_mirror", "0xc")
+DIRT_PACK_PAIR_BANKED(pack_pair_row_half_mirror, "row_half_mirror", "0xa")
+#undef DIRT_PACK_PAIR_BANKED
+
 template <int N>
 __device__ __forceinline__ float wave_reduce_scatter(const float* val, int lane)
 {
     static_assert(N == 16 || N == 24, "16 or 24 values");
-    constexpr int ROW_MIRROR = 0x140, ROW_HALF_MIRROR = 0x141, QUAD_MIRROR = 0x1B /* [3,2,1,0] */, QUAD_SWAP = 0xB1 /* [1,0,3,2] */;
-    const bool u8 = (lane & 8) != 0, u4 = (lane & 4) != 0, u2 = (lane & 2) != 0, u1 = (lane & 1) != 0;
+    constexpr int QUAD_MIRROR = 0x1B /* [3,2,1,0] */, QUAD_SWAP = 0xB1 /* [1,0,3,2] */;
+    const bool u2 = (lane & 2) != 0, u1 = (lane & 1) != 0;
     float a[N / 2], b[N / 4], c[N / 8];
 #pragma unroll
-    for (int i = 0; i < N / 2; ++i) a[i] = pack_pair<ROW_MIRROR>(val[i], val[i + N / 2], u8);
+    for (int i = 0; i < N / 2; ++i) a[i] = pack_pair_row_mirror(val[i], val[i + N / 2]);          // upper: lane bit 3
 #pragma unroll
-    for (int i = 0; i < N / 4; ++i) b[i] = pack_pair<ROW_HALF_MIRROR>(a[i], a[i + N / 4], u4);
+    for (int i = 0; i < N / 4; ++i) b[i] = pack_pair_row_half_mirror(a[i], a[i + N / 4]);        // upper: lane bit 2
 #pragma unroll
     for (int i = 0; i < N / 8; ++i) c[i] = pack_pair<QUAD_MIRROR>(b[i], b[i + N / 8], u2);
     float r0 = pack_pair<QUAD_SWAP>(c[0], c[1], u1);  // 16 values per row
@@ -180,6 +225,8 @@ __device__ __forceinline__ void write_debug(float* __restrict__ debug_thingy, co
     }
 }
 
+struct Float3 { float x, y, z; };   // three channels of a pixel: one 12-byte load / store (4-byte aligned)
+
 // Loads / stores at a 32-bit byte offset from a wave-uniform base: the address stays "scalar base + vector offset"
 // (one VGPR per address instead of two, no 64-bit vector arithmetic).
 template <class T>
@@ -193,18 +240,20 @@ __device__ __forceinline__ void st_off(void* base, uint32_t off, T v)
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + off) = v;
 }
 
-// grad_kernel<CSPEC>: CSPEC = 1, 3, 4: the channel count is that compile-time constant (4: with 16-byte aligned
-// pixel tensors), one workgroup per tile.  0: any channel count: the channels are cut into PASSES of whole channel groups
-// (dirt/rasterise_ops.py:148-152) -- p.n3 passes of one 3-channel group, then (p.has4) one pass {3, 1}, then 1-channel
-// passes -- and a workgroup takes one (tile, pass): the same three bodies over `pixels` with a runtime channel stride.
-// The passes of a tile are consecutive work items of one XCD (xcd_tile), so they run at about the same time next to the
-// same L2: a pass uses 12 of the 64 bytes of a 16-channel pixel, and what one pass brings in from HBM the others find
-// there.  grad_vertices is summed over the groups by the atomics (dirt/rasterise_ops.py:167-171).
+// grad_kernel<CSPEC, STRIDED>: a workgroup works on CSPEC = 1, 3 or 4 channels (4 = a 3-channel group and a single) of
+// one tile.  Not STRIDED: that is the image's channel count, a compile-time constant (4: with 16-byte aligned pixel
+// tensors).  STRIDED: any channel count, cut into PASSES of whole channel groups (dirt/rasterise_ops.py:148-152): the
+// launch covers p.npasses passes of this shape, starting at channel p.c_first, and a workgroup takes one (tile, pass)
+// over `pixels` with a runtime channel stride.  The passes of a tile are consecutive work items of one XCD (xcd_tile),
+// so they run at about the same time next to the same L2: a pass uses 12 of the 64 bytes of a 16-channel pixel, and
+// what one pass brings in from HBM the others find there.  grad_vertices is summed over the groups by the atomics
+// (dirt/rasterise_ops.py:167-171).
 // DEBUG: also write the reference's diagnostic output debug_thingy.
-template <int CSPEC, bool DEBUG>
+template <int CSPEC, bool STRIDED, bool DEBUG>
 __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 {
-    constexpr int NPLANES = CSPEC ? CSPEC : 4;
+    static_assert(CSPEC == 1 || CSPEC == 3 || CSPEC == 4, "pass shapes");
+    constexpr int NPLANES = CSPEC;
     __shared__ __align__(16) float s_pix[NPLANES][PR][PS];  // the pass's channels of `pixels`, edge clamped
     __shared__ __align__(16) float2 s_vw[PR][VS];           // {clip_w, face} of every pixel of the halo'd tile
     __shared__ __align__(16) float2 s_inbox[GTHREADS / 64][ICELLS];  // per wave: (fx, fy) sent to each pixel of its region + ring
@@ -218,21 +267,18 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int iib = blockIdx.y;
-    const int H = p.H, W = p.W, C = CSPEC ? CSPEC : p.C;
+    const int H = p.H, W = p.W, C = STRIDED ? p.C : CSPEC;
     const size_t frame = (size_t)H * W;
-    // this workgroup's tile and pass: `shape` channels starting at channel cbase
-    int tile, shape = CSPEC, cbase = 0;
-    if constexpr (CSPEC != 0) {
+    // this workgroup's tile and pass: CSPEC channels starting at channel cbase
+    int tile, cbase = 0;
+    if constexpr (!STRIDED) {
         tile = xcd_tile((int)blockIdx.x, p.tiles_x * p.tiles_y);
     } else {
         const int item = xcd_tile((int)blockIdx.x, p.tiles_x * p.tiles_y * p.npasses);
         tile = item / p.npasses;
-        const int pass = item - tile * p.npasses;
-        if (pass < p.n3) { shape = 3; cbase = 3 * pass; }
-        else if (p.has4 && pass == p.n3) { shape = 4; cbase = 3 * p.n3; }
-        else { shape = 1; cbase = 3 * p.n3 + 4 * p.has4 + (pass - p.n3 - p.has4); }
+        cbase = p.c_first + (item - tile * p.npasses) * (CSPEC == 1 ? 1 : 3);
     }
-    const bool aligned16 = CSPEC == 4 ? true : (p.pixels_aligned16 != 0 && (cbase & 3) == 0);
+    const bool aligned16 = (!STRIDED && CSPEC == 4) ? true : (p.pixels_aligned16 != 0 && (cbase & 3) == 0);
     const int x0 = (tile % p.tiles_x) * GT, y0 = (tile / p.tiles_x) * GT;
 
     // Wave-uniform bases at the first staged row of the tile (row0), so that every per-lane address is a small
@@ -281,6 +327,9 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             if (nch == 4 && (C & 3) == 0 && aligned16) {
                 const float4 q = ld_off<float4>(pixels_t, off);
                 v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
+            } else if (nch == 3) {
+                const Float3 q = ld_off<Float3>(pixels_t, off);
+                v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = 0.f;
             } else {
 #pragma unroll
                 for (int ch = 0; ch < PC; ++ch) v[k][ch] = ch < nch ? ld_off<float>(pixels_t, off + 4u * ch) : 0.f;
@@ -311,7 +360,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     //      Halo positions outside the frame are clamped; they are only ever consulted for interior pixels, whose
     //      neighbours are inside the frame. ----
     float stage_v[PITEMS][PC];
-    stage_load(shape, stage_v);
+    stage_load(CSPEC, stage_v);
     {
         constexpr int VITEMS = (PR * PR + GTHREADS - 1) / GTHREADS;
         float2 rec[VITEMS];
@@ -345,47 +394,59 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { fxy[j][0] = 0.f; fxy[j][1] = 0.f; }
 
-    // ---- the face loop.  The wave walks the distinct faces among its pixels (key[j], -1 = none) and, with POS, among
-    //      the ring cells it holds (lkey): per face every lane forms its masked partial sums -- POS: 3 vertices x
-    //      (x, y, w) from b_k * fpos; NCHV colour channels: 3 vertices x b_k * g -- the sums are reduced across the wave
-    //      (wave_reduce_scatter) and one atomic instruction adds the totals to the face's three vertices. ----
-    auto face_loop = [&](auto nchv_tag, auto pos_tag, const auto& g, const int (&key)[4], const bool (&covered)[4],
+    // ---- the face loop.  The wave walks the distinct faces among its pixels (key[j], -1 = none) and among the ring
+    //      cells it holds (lkey): per face every lane forms its masked partial sums -- per vertex k the S values
+    //      b_k * (fx, fy, fw, g_0 .. g_NCHV-1 [, 0]) (S = 3 + NCHV rounded up to even), as S / 2 packed pairs: one
+    //      v_pk_fma_f32 per pair and pixel -- the 3 S sums are reduced across the wave (wave_reduce_scatter) and one
+    //      atomic instruction adds the totals to the face's three vertices. ----
+    auto face_loop = [&](auto nchv_tag, const auto& g, const int (&key)[4], const bool (&covered)[4],
                          const float (&fpos)[4][3], const int (&lkey)[2], const float (&lb)[2][3], const float (&lf)[2][3]) {
         constexpr int NCHV = decltype(nchv_tag)::value;
-        constexpr bool POS = decltype(pos_tag)::value;
-        constexpr int NP = POS ? 9 : 0;
-        constexpr int NV = NP + 3 * NCHV;           // values per face
+        constexpr int S = (3 + NCHV + 1) & ~1;      // values per vertex (padded to whole pairs)
+        constexpr int HP = S / 2;                   // ... as pairs
+        constexpr int NV = 3 * S;                   // values per face
         constexpr int NR = NV <= 16 ? 16 : 24;      // ... padded to what the wave reduction takes
-        // this lane's role: it adds value role_v of the face (reduce_value_of_lane): v < NP: component v % 3 (x, y, w) of
-        // grad_vertices of vertex v / 3; else colour (v - NP) % NCHV of vertex (v - NP) / NCHV
+        static_assert(NV <= NR, "");
+        // this lane's role: it adds value role_v of the face (reduce_value_of_lane): vertex role_v / S, component
+        // c = role_v % S: c < 3: (x, y, w) of grad_vertices; else colour c - 3
         const int role_v = reduce_value_of_lane<NR>(lane);
-        const bool role_valid = role_v >= 0 && role_v < NV;
-        const bool role_pos = role_v < NP;
-        const int role_k = role_pos ? role_v / 3 : (role_v - NP) / (NCHV ? NCHV : 1);
-        const int role_e = role_pos ? (role_v % 3 == 2 ? 3 : role_v % 3) : (role_v - NP) % (NCHV ? NCHV : 1);
-        float* const role_base = role_pos ? grad_vertices + role_e : grad_vertex_colors + role_e;
+        const int role_k = role_v >= 0 ? role_v / S : 0, role_c = role_v >= 0 ? role_v % S : S;
+        const bool role_valid = role_v >= 0 && role_v < NV && role_c < 3 + NCHV;
+        const bool role_pos = role_c < 3;
+        float* const role_base = role_pos ? grad_vertices + (role_c == 2 ? 3 : role_c) : grad_vertex_colors + (role_c - 3);
         const uint32_t role_stride = role_pos ? 16u : pixel_bytes;
+        // the factors of a pixel, in pairs
+        float2v fp[4][HP];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float f[S];
+            f[0] = fpos[j][0]; f[1] = fpos[j][1]; f[2] = fpos[j][2];
+#pragma unroll
+            for (int c = 3; c < S; ++c) f[c] = c - 3 < NCHV ? g[j][c - 3 < NCHV ? c - 3 : 0] : 0.f;
+#pragma unroll
+            for (int h = 0; h < HP; ++h) { fp[j][h].x = f[2 * h]; fp[j][h].y = f[2 * h + 1]; }
+        }
         // pending pixels / ring cells as wave-wide masks (scalar registers)
         unsigned long long pend[6];
 #pragma unroll
         for (int j = 0; j < 4; ++j) pend[j] = __builtin_amdgcn_ballot_w64(covered[j]);
-        pend[4] = POS ? __builtin_amdgcn_ballot_w64(lkey[0] >= 0) : 0ull;
-        pend[5] = POS ? __builtin_amdgcn_ballot_w64(lkey[1] >= 0) : 0ull;
+        pend[4] = __builtin_amdgcn_ballot_w64(lkey[0] >= 0);
+        pend[5] = __builtin_amdgcn_ballot_w64(lkey[1] >= 0);
         for (;;) {
             int K;
             if (pend[0]) K = __builtin_amdgcn_readlane(key[0], __ffsll((long long)pend[0]) - 1);
             else if (pend[1]) K = __builtin_amdgcn_readlane(key[1], __ffsll((long long)pend[1]) - 1);
             else if (pend[2]) K = __builtin_amdgcn_readlane(key[2], __ffsll((long long)pend[2]) - 1);
             else if (pend[3]) K = __builtin_amdgcn_readlane(key[3], __ffsll((long long)pend[3]) - 1);
-            else if (POS && pend[4]) K = __builtin_amdgcn_readlane(lkey[0], __ffsll((long long)pend[4]) - 1);
-            else if (POS && pend[5]) K = __builtin_amdgcn_readlane(lkey[1], __ffsll((long long)pend[5]) - 1);
+            else if (pend[4]) K = __builtin_amdgcn_readlane(lkey[0], __ffsll((long long)pend[4]) - 1);
+            else if (pend[5]) K = __builtin_amdgcn_readlane(lkey[1], __ffsll((long long)pend[5]) - 1);
             else break;
             // the face's vertex indices (a wave-uniform address: requested now, needed after the reduction)
             const int32_t* fk = faces + (size_t)(uint32_t)K * 3;
             const int v0 = fk[0], v1 = fk[1], v2 = fk[2];
-            float acc[NR];
+            float2v accp[NR / 2];
 #pragma unroll
-            for (int v = NV; v < NR; ++v) acc[v] = 0.f;
+            for (int i = NV / 2; i < NR / 2; ++i) accp[i] = float2v{0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool m = key[j] == K;
@@ -393,32 +454,29 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float bm = m ? bk[j][k] : 0.f;
-                    if constexpr (POS) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) acc[3 * k + c] = j == 0 ? bm * fpos[j][c] : fmaf(bm, fpos[j][c], acc[3 * k + c]);
-                    }
-#pragma unroll
-                    for (int ch = 0; ch < NCHV; ++ch)
-                        acc[NP + NCHV * k + ch] = j == 0 ? bm * g[j][ch] : fmaf(bm, g[j][ch], acc[NP + NCHV * k + ch]);
+                    for (int h = 0; h < HP; ++h)
+                        accp[k * HP + h] = j == 0 ? pk_mul_scalar(bm, fp[j][h]) : pk_fma_scalar(bm, fp[j][h], accp[k * HP + h]);
                 }
             }
-            if constexpr (POS) {
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const bool m = lkey[e] == K;
-                    const unsigned long long mm = __builtin_amdgcn_ballot_w64(m);
-                    if (mm != 0ull) {
-                        pend[4 + e] &= ~mm;
+            for (int e = 0; e < 2; ++e) {
+                const bool m = lkey[e] == K;
+                const unsigned long long mm = __builtin_amdgcn_ballot_w64(m);
+                if (mm != 0ull) {
+                    pend[4 + e] &= ~mm;
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const float bm = m ? lb[e][k] : 0.f;
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) acc[3 * k + c] = fmaf(bm, lf[e][c], acc[3 * k + c]);
-                        }
+                    for (int k = 0; k < 3; ++k) {
+                        const float bm = m ? lb[e][k] : 0.f;
+                        accp[k * HP] = pk_fma_scalar(bm, float2v{lf[e][0], lf[e][1]}, accp[k * HP]);
+                        accp[k * HP + 1].x = fmaf(bm, lf[e][2], accp[k * HP + 1].x);
                     }
                 }
             }
             GCOUNT(1, 1);
+            float acc[NR];
+#pragma unroll
+            for (int i = 0; i < NR / 2; ++i) { acc[2 * i] = accp[i].x; acc[2 * i + 1] = accp[i].y; }
             const float total = wave_reduce_scatter<NR>(acc, lane);
             const int vsel = role_k == 0 ? v0 : (role_k == 1 ? v1 : v2);
             if (role_valid && total != 0.f)
@@ -486,6 +544,11 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                     wide = true;
                 }
             }
+            if constexpr (NCH == 3) {
+                const Float3 q = ld_off<Float3>(gpix_t, off);
+                g[j][0] = q.x; g[j][1] = q.y; g[j][2] = q.z;
+                wide = true;
+            }
             if (!wide) {
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) g[j][ch] = ld_off<float>(gpix_t, off + 4u * ch);
@@ -501,7 +564,9 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         //      previous tensor row), streamed per channel into what is needed of it: the direction choice of :185 from the
         //      L1 norms (all three "channels" of the reference's Vec3, in its summation order) and dL/dx, dL/dy of
         //      :203-208 ----
-        uint32_t horiz_bits = 0;  // bit 4 * group + j: the pixel's dilation axis is x
+        // Per-lane predicates are kept as wave-wide lane masks in scalar registers from here on: what combines them is
+        // then scalar work (s_and / s_or), and the vector unit -- what bounds this kernel -- only compares and selects.
+        lanemask horiz_m[NG][4];  // [group][j]: the pixel's dilation axis is x
         float dLx[NG][4], dLy[NG][4];
         {
             float l1x[4], l1y[4];
@@ -569,15 +634,20 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                 }
                 if (last_of_group) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) horiz_bits |= (l1x[j] > l1y[j]) ? (1u << (4 * gi + j)) : 0u;  // :185
+                    for (int j = 0; j < 4; ++j) horiz_m[gi][j] = __builtin_amdgcn_ballot_w64(l1x[j] > l1y[j]);  // :185
                     if (single && !q1_intended && x0 + GT + 3 > W) {  // wave-uniform: only tiles on the right image border
                         uint32_t ib = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ib |= (interior[j] && xs + j + 3 > W - 1) ? (1u << j) : 0u;
-                        if (__builtin_amdgcn_ballot_w64(ib != 0u) != 0ull)
-                            horiz_bits = alias_wrap_fixup(p.pixels, p.B, H, W, C, iib, y, xs, cbase + ch, ib, horiz_bits, 4 * gi);
+                        if (__builtin_amdgcn_ballot_w64(ib != 0u) != 0ull) {
+                            uint32_t bits = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) bits |= __builtin_amdgcn_inverse_ballot_w64(horiz_m[gi][j]) ? (1u << j) : 0u;
+                            bits = alias_wrap_fixup(p.pixels, p.B, H, W, C, iib, y, xs, cbase + ch, ib, bits, 0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) horiz_m[gi][j] = __builtin_amdgcn_ballot_w64(((bits >> j) & 1u) != 0u);
+                        }
                     }
-                    asm volatile("" : "+v"(horiz_bits));  // decided here: the norms' registers are free again
                 }
                 __builtin_amdgcn_sched_barrier(0);  // one channel's taps at a time
             }
@@ -621,6 +691,10 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                     wide = true;
                 }
             }
+            if constexpr (NCH == 3) {
+                st_off<Float3>(gbk_t, off, covered[j] ? Float3{0.f, 0.f, 0.f} : Float3{g[j][0], g[j][1], g[j][2]});
+                wide = true;
+            }
             if (!wide) {
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) st_off<float>(gbk_t, off + 4u * ch, covered[j] ? 0.f : g[j][ch]);
@@ -628,55 +702,57 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         }
 
         // ---- dilation (:155-194).  A pixel takes the fragment of the neighbour n at +d, else at -d, when that neighbour
-        //      is covered, is another face (:86-89) and is closer (:165); d is +-x or +-y.  The four tests of a pixel do not
-        //      depend on the channel group, and the horizontal ones are shared by adjacent pixels of the strip. ----
-        bool ok_l[4], ok_r[4], ok_u[4], ok_d[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float wl = j == 0 ? w_l : w_own[j - 1], wr = j == 3 ? w_r : w_own[j + 1];
-            const int fl = j == 0 ? f_l : f_own[j - 1], fr = j == 3 ? f_r : f_own[j + 1];
-            // the pixel's own face as the state tile has it (an uncovered pixel, -1, differs from any face)
-            ok_l[j] = interior[j] & (fl >= 0) & (fl != f_own[j]) & (w_own[j] > wl);
-            ok_r[j] = interior[j] & (fr >= 0) & (fr != f_own[j]) & (w_own[j] > wr);
-            ok_u[j] = interior[j] & (f_up[j] >= 0) & (f_up[j] != f_own[j]) & (w_own[j] > w_up[j]);
-            ok_d[j] = interior[j] & (f_dn[j] >= 0) & (f_dn[j] != f_own[j]) & (w_own[j] > w_dn[j]);
-        }
-
+        //      is covered, is another face (:86-89) and is closer (:165); d is +-x or +-y.  An uncovered neighbour has
+        //      clip_w = +inf (the clear value), so "closer" already says it is covered.  The four tests of a pixel do not
+        //      depend on the channel group, and the horizontal ones are shared by adjacent pixels of the strip.
         // ---- position factors (:196-232): the gradients of vertex k are b_k * (fx, fy, fw) with
         //          fx = dL_dx * (W/2) / w,  fy = dL_dy * (H/2) / w,  fw = -(fx * ndc_x + fy * ndc_y)
         //      (:210-222: clip_x = sum b_k * vertex_k.x is the fragment's own clip position = its NDC position times
         //      clip_w -- perspective-correct barycentrics -- so no vertex gather is needed; one v_rcp_f32, 1 ulp; agrees to
         //      float rounding), everything taken at the pixel whose fragment is used.  (fx, fy) are summed per such
         //      TARGET pixel -- own pixels in registers, neighbours through the inbox -- and fw is formed once per pixel. ----
+        const lanemask parity0 = __builtin_amdgcn_ballot_w64(((xs + y) & 1) == 0);  // pixel 0 tries +x / up first (:186-191)
+        const float2v half_size = float2v{.5f * width_f, .5f * height_f};
 #pragma unroll
-        for (int gi = 0; gi < NG; ++gi) {
+        for (int j = 0; j < 4; ++j) {
+            const float wl = j == 0 ? w_l : w_own[j - 1], wr = j == 3 ? w_r : w_own[j + 1];
+            const int fl = j == 0 ? f_l : f_own[j - 1], fr = j == 3 ? f_r : f_own[j + 1];
+            // the pixel's own face as the state tile has it (an uncovered pixel, -1, differs from any face)
+            const lanemask m_in = __builtin_amdgcn_ballot_w64(interior[j]);
+            const lanemask ok_l = m_in & __builtin_amdgcn_ballot_w64(fl != f_own[j]) & __builtin_amdgcn_ballot_w64(w_own[j] > wl);
+            const lanemask ok_r = m_in & __builtin_amdgcn_ballot_w64(fr != f_own[j]) & __builtin_amdgcn_ballot_w64(w_own[j] > wr);
+            const lanemask ok_u = m_in & __builtin_amdgcn_ballot_w64(f_up[j] != f_own[j]) & __builtin_amdgcn_ballot_w64(w_own[j] > w_up[j]);
+            const lanemask ok_d = m_in & __builtin_amdgcn_ballot_w64(f_dn[j] != f_own[j]) & __builtin_amdgcn_ballot_w64(w_own[j] > w_dn[j]);
+            const lanemask m_cov = __builtin_amdgcn_ballot_w64(covered[j]);
+            const lanemask pos = (j & 1) ? ~parity0 : parity0;   // first attempt towards +x / up (:191), else -x / down
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int gi = 0; gi < NG; ++gi) {
                 // direction: x if L1(Sx) > L1(Sy) else y (:185), negated on odd (x + y) (:186-190).  The reference's
                 // offsets are in GL buffer orientation (y up): tensor row = y - offset_y.
-                const bool horiz = (horiz_bits >> (4 * gi + j)) & 1u;
-                const bool pos = ((xs + j + y) & 1) == 0;                       // first attempt towards +x / up (:191), else -x / down
-                const bool ok_a = horiz ? (pos ? ok_r[j] : ok_l[j]) : (pos ? ok_u[j] : ok_d[j]);
-                const bool ok_b = horiz ? (pos ? ok_l[j] : ok_r[j]) : (pos ? ok_d[j] : ok_u[j]);
-                const bool dilated = ok_a | ok_b;                                // the opposite direction if the first failed (:192-193)
-                const bool fwd = pos == ok_a;                                    // the neighbour taken lies at +x / up
-                const float w_h = fwd ? (j == 3 ? w_r : w_own[j == 3 ? 3 : j + 1]) : (j == 0 ? w_l : w_own[j == 0 ? 0 : j - 1]);
-                const float w_v = fwd ? w_up[j] : w_dn[j];
-                const float clip_w = dilated ? (horiz ? w_h : w_v) : w_own[j];
+                const lanemask hz = horiz_m[gi][j];
+                const lanemask ok_a = (hz & ((pos & ok_r) | (~pos & ok_l))) | (~hz & ((pos & ok_u) | (~pos & ok_d)));
+                const lanemask ok_b = (hz & ((pos & ok_l) | (~pos & ok_r))) | (~hz & ((pos & ok_d) | (~pos & ok_u)));
+                const lanemask dil = ok_a | ok_b;      // the opposite direction if the first failed (:192-193)
+                const lanemask fwd = ~(pos ^ ok_a);    // the neighbour taken lies at +x / up
+                float clip_w = w_own[j];
+                clip_w = __builtin_amdgcn_inverse_ballot_w64(dil & hz & fwd) ? wr : clip_w;
+                clip_w = __builtin_amdgcn_inverse_ballot_w64(dil & hz & ~fwd) ? wl : clip_w;
+                clip_w = __builtin_amdgcn_inverse_ballot_w64(dil & ~hz & fwd) ? w_up[j] : clip_w;
+                clip_w = __builtin_amdgcn_inverse_ballot_w64(dil & ~hz & ~fwd) ? w_dn[j] : clip_w;
+                const bool dilated = __builtin_amdgcn_inverse_ballot_w64(dil);
                 if constexpr (DEBUG) {
                     if (cbase == 0 && gi == 0 && in_px[j]) write_debug(p.debug_thingy, p.grad_pixels, p.B, H, W, C, iib, y, xs + j, G0, dilated);
                 }
                 const float rcp_w = __builtin_amdgcn_rcpf(clip_w);
-                const bool contributes = dilated | covered[j];
-                const float fx = contributes ? (dLx[gi][j] * (.5f * width_f)) * rcp_w : 0.f;
-                const float fy = contributes ? (dLy[gi][j] * (.5f * height_f)) * rcp_w : 0.f;
-                fxy[j][0] += dilated ? 0.f : fx;
-                fxy[j][1] += dilated ? 0.f : fy;
+                float2v f = (float2v{dLx[gi][j], dLy[gi][j]} * half_size) * float2v{rcp_w, rcp_w};
+                const bool own = __builtin_amdgcn_inverse_ballot_w64(m_cov & ~dil);   // contributes to its own pixel
+                fxy[j][0] += own ? f.x : 0.f;
+                fxy[j][1] += own ? f.y : 0.f;
                 if (dilated) {  // few lanes: ds_add_f32 into the neighbour's cell
-                    const int step = horiz ? 1 : -IS;                            // +x, or up = the previous row
-                    float* cell = reinterpret_cast<float*>(inbox + (my_cell + j + (fwd ? step : -step)));
-                    atomicAdd(cell, fx);
-                    atomicAdd(cell + 1, fy);
+                    const int step = __builtin_amdgcn_inverse_ballot_w64(hz) ? 1 : -IS;   // +x, or up = the previous row
+                    float* cell = reinterpret_cast<float*>(inbox + (my_cell + j + (__builtin_amdgcn_inverse_ballot_w64(fwd) ? step : -step)));
+                    atomicAdd(cell, f.x);
+                    atomicAdd(cell + 1, f.y);
                 }
             }
         }
@@ -687,13 +763,10 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         float lb[2][3], lf[2][3];
         gather_positions(fpos, lkey, lb, lf);
         GMARK();  // 6 face loop starts
-        face_loop(integral_constant<int, NCH>{}, integral_constant<bool, true>{}, g, key, covered, fpos, lkey, lb, lf);
+        face_loop(integral_constant<int, NCH>{}, g, key, covered, fpos, lkey, lb, lf);
     };
 
-    if constexpr (CSPEC != 0) run_pass(integral_constant<int, CSPEC>{}, integral_constant<int, CSPEC == 1 ? 1 : 3>{});
-    else if (shape == 3) run_pass(integral_constant<int, 3>{}, integral_constant<int, 3>{});
-    else if (shape == 4) run_pass(integral_constant<int, 4>{}, integral_constant<int, 3>{});
-    else run_pass(integral_constant<int, 1>{}, integral_constant<int, 1>{});
+    run_pass(integral_constant<int, CSPEC>{}, integral_constant<int, CSPEC == 1 ? 1 : 3>{});
     GMARK();  // 7 done
 #ifdef DIRT_TRACE
     if (lane == 0 && g_trace_grad) {
@@ -713,24 +786,35 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     p.tiles_y = (p.H + GT - 1) / GT;
     p.pixels_aligned16 = ((reinterpret_cast<uintptr_t>(p.pixels) | reinterpret_cast<uintptr_t>(p.grad_pixels) |
                            reinterpret_cast<uintptr_t>(p.grad_background)) & 15u) == 0 ? 1 : 0;
-    // the common channel counts get kernels in which the pass / channel-group structure is static
-    const int cspec = (p.C == 4 && p.pixels_aligned16) ? 4 : (p.C == 3 ? 3 : (p.C == 1 ? 1 : 0));
-    // any other channel count: passes of whole channel groups (groups of 3 while >= 3 channels remain, then singles,
-    // dirt/rasterise_ops.py:148-152); the last 3-group and the first single share a pass
-    const int groups3 = p.C / 3, singles = p.C % 3;
-    p.has4 = (groups3 >= 1 && singles >= 1) ? 1 : 0;
-    p.n3 = groups3 - p.has4;
-    p.npasses = cspec ? 1 : p.n3 + p.has4 + (singles - p.has4);
-    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.npasses), (unsigned)p.B), block(GTHREADS);
-#define DIRT_LAUNCH_GRAD(DBG_)                                                                          \
-    do {                                                                                               \
-        if (cspec == 4) hipLaunchKernelGGL((grad_kernel<4, DBG_>), grid, block, 0, stream, p);         \
-        else if (cspec == 3) hipLaunchKernelGGL((grad_kernel<3, DBG_>), grid, block, 0, stream, p);    \
-        else if (cspec == 1) hipLaunchKernelGGL((grad_kernel<1, DBG_>), grid, block, 0, stream, p);    \
-        else hipLaunchKernelGGL((grad_kernel<0, DBG_>), grid, block, 0, stream, p);                    \
+#ifdef DIRT_TRACE
+    const size_t dyn_lds = getenv("DIRT_TRACE_DYN_LDS") ? (size_t)atoi(getenv("DIRT_TRACE_DYN_LDS")) : 0;  // occupancy experiments
+#else
+    const size_t dyn_lds = 0;
+#endif
+    const dim3 block(GTHREADS);
+    const unsigned ntiles = (unsigned)(p.tiles_x * p.tiles_y);
+#define DIRT_LAUNCH_GRAD(SHAPE_, STRIDED_)                                                                       \
+    do {                                                                                                        \
+        const dim3 grid(ntiles * (unsigned)p.npasses, (unsigned)p.B);                                           \
+        if (p.debug_thingy && p.c_first == 0)                                                                   \
+            hipLaunchKernelGGL((grad_kernel<SHAPE_, STRIDED_, true>), grid, block, dyn_lds, stream, p);         \
+        else                                                                                                    \
+            hipLaunchKernelGGL((grad_kernel<SHAPE_, STRIDED_, false>), grid, block, dyn_lds, stream, p);        \
     } while (0)
-    if (p.debug_thingy) DIRT_LAUNCH_GRAD(true);
-    else DIRT_LAUNCH_GRAD(false);
+    p.c_first = 0; p.npasses = 1;
+    // the common channel counts: kernels in which the channel count is a compile-time constant
+    if (p.C == 4 && p.pixels_aligned16) DIRT_LAUNCH_GRAD(4, false);
+    else if (p.C == 3) DIRT_LAUNCH_GRAD(3, false);
+    else if (p.C == 1) DIRT_LAUNCH_GRAD(1, false);
+    else {
+        // any other channel count: passes of whole channel groups (groups of 3 while >= 3 channels remain, then singles,
+        // dirt/rasterise_ops.py:148-152); the last 3-group and the first single share a pass.  One launch per pass shape.
+        const int groups3 = p.C / 3, singles = p.C % 3;
+        const int has4 = (groups3 >= 1 && singles >= 1) ? 1 : 0;
+        if (groups3 - has4 > 0) { p.c_first = 0; p.npasses = groups3 - has4; DIRT_LAUNCH_GRAD(3, true); }
+        if (has4) { p.c_first = 3 * (groups3 - 1); p.npasses = 1; DIRT_LAUNCH_GRAD(4, true); }
+        if (singles - has4 > 0) { p.c_first = 3 * groups3 + has4; p.npasses = singles - has4; DIRT_LAUNCH_GRAD(1, true); }
+    }
 #undef DIRT_LAUNCH_GRAD
     return hipGetLastError();
 }

@@ -78,7 +78,7 @@ struct GradParams {
     unsigned flags;
     int tiles_x, tiles_y;      // filled by launch_grad
     int pixels_aligned16;      // the [B,H,W,C] tensors may be accessed with 16-byte loads / stores, filled by launch_grad
-    int n3, has4, npasses;     // channel passes of the any-channel-count kernel (see grad_kernel), filled by launch_grad
+    int c_first, npasses;      // the launch's channel passes (see grad_kernel<CSPEC, STRIDED>), filled by launch_grad
 };
 
 BinGrid make_bin_grid(int H, int W);

@@ -23,7 +23,7 @@ def run(budget=None, max_cases=None, seed=0, hard=False, max_dim=None):
     top = max_dim or (700 if hard else 400)
     while (budget is None or time.time() - t0 < budget) and (max_cases is None or n < max_cases):
         H, W = int(rng.integers(1, top)), int(rng.integers(1, top))
-        C = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 10]))
+        C = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 16]))
         kind = rng.choice(['split', 'shared', 'hostile', 'tiny'], p=[0.1, 0.1, 0.7, 0.1] if hard else None)
         seed_ = int(rng.integers(0, 1 << 30))
         if kind == 'hostile':

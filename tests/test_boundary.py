@@ -153,7 +153,7 @@ def test_channel_groups_follow_the_reference():
     assert ref_groups(5) == [(0, 3), (3, 4), (4, 5)]
     src = open(os.path.join(ROOT, 'dirt_amd', 'csrc', 'dirt_grad.hip')).read()
     # launch_grad: groups of 3 while >= 3 channels remain, then singles (the last 3-group and the first single share a pass)
-    assert 'const int groups3 = p.C / 3, singles = p.C % 3;' in src
+    assert "const int groups3 = p.C / 3, singles = p.C % 3;" in src
 
 
 def test_scene_generators_are_deterministic():
