@@ -85,16 +85,17 @@ constexpr int IS = 34;                  // inbox row stride (float2 cells): cell
 constexpr int ICELLS = 10 * IS + 4;     // ... of a wave's 32 x 8 region and the one-pixel ring around it (a multiple of 2: 16-byte cells pairs)
 constexpr int RING = 2 * 34 + 2 * 8;    // ring cells: what the wave's pixels sent to pixels of other waves
 
-// Reduce N (16 or 24) per-lane values across the 64 lanes of the wave: a transposing butterfly.  Inside a DPP row of 16
-// lanes, every level pairs lane l with its mirror image (row_mirror, row_half_mirror, the two quad permutations) and
-// pairs value i with value i + (half of what is left): a lane keeps one of the two values, sends the other to its partner
-// and adds what it receives -- two selects and one DPP add per pair, and half as many registers after each level.  After
-// four levels one or two registers hold, per row, 16 different values in 16 lanes; v_permlane32_swap and
-// v_permlane16_swap then add the four rows.  ~70 instructions for 24 values (six plain DPP reductions per value would
-// be 144).  Returns the totals in these lanes (c = lane & 15, bits b3 b2 b1 b0):
-//   N = 16: lanes 0-15:  value  b0 + 2 b1 + 4 b2 + 8 b3
-//   N = 24: lanes 0-15:  value  b0 + 3 b1 + 6 b2 + 12 b3;   lanes 32-47 (b0 = 0): value 2 + 3 b1 + 6 b2 + 12 b3
-// (reduce_value_of_lane() below); other lanes hold copies or nothing of interest.
+// Reduce N (16 or 24) per-lane values over the lanes of the wave, separately for its two lane GROUPS (lane bit 2: the
+// left and the right 16 x 8 pixels of the wave's region, see the face loop): a transposing butterfly.  At every level a
+// lane is paired with the lane that differs in one lane bit, and value i with value i + (half of what is left): the lane
+// keeps one of the two values, sends the other to its partner and adds what it receives, so that registers halve while
+// lanes specialise.  Inside a DPP row of 16 lanes: bit 3 (row_ror:8; the "upper" lanes are whole DPP banks, so the pair
+// takes two bank-masked DPP adds and no selects), bit 1 and bit 0 (quad permutations: two selects and a DPP add); then
+// v_permlane32_swap and v_permlane16_swap add the four rows.  ~60 instructions for 24 values x 2 groups (plain DPP
+// reductions of every value would be several hundred).  The total of value
+//     v = i(row) + b0 * N/8 + b1 * N/4 + b3 * N/2        (b_k: bit k of the lane;  i: N = 24: rows 0, 2, 1 -> 0, 1, 2;
+//                                                          N = 16: rows 0, 2 -> 0, 1; other rows hold copies)
+// over the lanes of group b2 ends up in that lane (reduce_value_of_lane() below).
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
 {
@@ -108,56 +109,55 @@ __device__ __forceinline__ float pack_pair(float lo, float hi, bool upper)
     return keep + dpp_mov<CTRL>(send);
 }
 
-// The same for the two levels whose "upper" lanes are whole DPP banks (lanes 8-15 of a row: banks 2, 3; lanes 4-7 and
-// 12-15: banks 1, 3): lo + partner's lo everywhere, then hi + partner's hi written to the upper banks only -- two
-// instructions, no selects.  (Written as assembly: the bank-masked form of a DPP add has no builtin.  A DPP operand
-// written by the preceding VALU instruction needs two wait states: the leading s_nop.)
-#define DIRT_PACK_PAIR_BANKED(NAME, CTRL_TEXT, UPPER_BANKS)                                                              \
-    __device__ __forceinline__ float NAME(float lo, float hi)                                                            \
-    {                                                                                                                   \
-        float r;                                                                                                        \
-        asm("s_nop 1\n\t"                                                                                               \
-            "v_add_f32_dpp %0, %1, %1 " CTRL_TEXT " row_mask:0xf bank_mask:0xf\n\t"                                      \
-            "v_add_f32_dpp %0, %2, %2 " CTRL_TEXT " row_mask:0xf bank_mask:" UPPER_BANKS                                 \
-            : "=&v"(r) : "v"(lo), "v"(hi));                                                                             \
-        return r;                                                                                                       \
-    }
-DIRT_PACK_PAIR_BANKED(pack_pair_row_mirror, "row_mirror", "0xc")
-DIRT_PACK_PAIR_BANKED(pack_pair_row_half_mirror, "row_half_mirror", "0xa")
-#undef DIRT_PACK_PAIR_BANKED
+// The same for the level whose "upper" lanes are whole DPP banks (lanes 8-15 of a row: banks 2, 3): lo + partner's lo
+// everywhere, then hi + partner's hi written to the upper banks only -- two instructions, no selects.  (Written as
+// assembly: the bank-masked form of a DPP add has no builtin.  A DPP operand written by the preceding VALU instruction
+// needs two wait states: the leading s_nop.)
+__device__ __forceinline__ float pack_pair_bit3(float lo, float hi)
+{
+    float r;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 
 template <int N>
 __device__ __forceinline__ float wave_reduce_scatter(const float* val, int lane)
 {
     static_assert(N == 16 || N == 24, "16 or 24 values");
-    constexpr int QUAD_MIRROR = 0x1B /* [3,2,1,0] */, QUAD_SWAP = 0xB1 /* [1,0,3,2] */;
+    constexpr int QUAD_XOR2 = 0x4E /* [2,3,0,1] */, QUAD_XOR1 = 0xB1 /* [1,0,3,2] */;
     const bool u2 = (lane & 2) != 0, u1 = (lane & 1) != 0;
     float a[N / 2], b[N / 4], c[N / 8];
 #pragma unroll
-    for (int i = 0; i < N / 2; ++i) a[i] = pack_pair_row_mirror(val[i], val[i + N / 2]);          // upper: lane bit 3
+    for (int i = 0; i < N / 2; ++i) a[i] = pack_pair_bit3(val[i], val[i + N / 2]);
 #pragma unroll
-    for (int i = 0; i < N / 4; ++i) b[i] = pack_pair_row_half_mirror(a[i], a[i + N / 4]);        // upper: lane bit 2
+    for (int i = 0; i < N / 4; ++i) b[i] = pack_pair<QUAD_XOR2>(a[i], a[i + N / 4], u2);
 #pragma unroll
-    for (int i = 0; i < N / 8; ++i) c[i] = pack_pair<QUAD_MIRROR>(b[i], b[i + N / 8], u2);
-    float r0 = pack_pair<QUAD_SWAP>(c[0], c[1], u1);  // 16 values per row
-    float r1 = r0;
-    if (N == 24) r1 = c[2] + dpp_mov<QUAD_SWAP>(c[2]);  // 8 values per row, each in two lanes
+    for (int i = 0; i < N / 8; ++i) c[i] = pack_pair<QUAD_XOR1>(b[i], b[i + N / 8], u1);
     // the four rows: halves, then rows of a half
-    auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r1), false, false);
-    const float t = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);   // lanes 0-31: r0 (rows 0+2 | 1+3), lanes 32-63: r1
-    auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
-    return __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+    auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(c[1]), false, false);
+    const float t0 = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);   // lanes 0-31: c[0] (rows 0+2 | 1+3), lanes 32-63: c[1]
+    float t1 = t0;
+    if (N == 24) {
+        auto s32b = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[2]), __float_as_uint(c[2]), false, false);
+        t1 = __uint_as_float(s32b[0]) + __uint_as_float(s32b[1]);         // every lane: c[2], the two halves added
+    }
+    auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(t0), __float_as_uint(t1), false, false);
+    return __uint_as_float(s16[0]) + __uint_as_float(s16[1]);             // rows 0, 2: t0's totals; rows 1, 3: t1's
 }
 
-// The value whose total wave_reduce_scatter<N> leaves in `lane`, or -1.
+// The value whose total (over the lane's group) wave_reduce_scatter<N> leaves in `lane`, or -1.
 template <int N>
 __device__ __forceinline__ int reduce_value_of_lane(int lane)
 {
-    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, row = lane >> 4;
-    if (N == 16) return row == 0 ? b0 + 2 * b1 + 4 * b2 + 8 * b3 : -1;
-    if (row == 0) return b0 + 3 * b1 + 6 * b2 + 12 * b3;
-    if (row == 2 && b0 == 0) return 2 + 3 * b1 + 6 * b2 + 12 * b3;
-    return -1;
+    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b3 = (lane >> 3) & 1, row = lane >> 4;
+    int i = -1;
+    if (row == 0) i = 0;
+    if (row == 2) i = 1;
+    if (N == 24 && row == 1) i = 2;
+    return i < 0 ? -1 : i + b0 * (N / 8) + b1 * (N / 4) + b3 * (N / 2);
 }
 
 // Quirk Q1 at the right image border: for the pixels of a strip (first column xs, row y) flagged in `which`, the
@@ -427,23 +427,35 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             for (int h = 0; h < HP; ++h) { fp[j][h].x = f[2 * h]; fp[j][h].y = f[2 * h + 1]; }
         }
         // pending pixels / ring cells as wave-wide masks (scalar registers)
-        unsigned long long pend[6];
+        lanemask pend[6];
 #pragma unroll
         for (int j = 0; j < 4; ++j) pend[j] = __builtin_amdgcn_ballot_w64(covered[j]);
         pend[4] = __builtin_amdgcn_ballot_w64(lkey[0] >= 0);
         pend[5] = __builtin_amdgcn_ballot_w64(lkey[1] >= 0);
+        constexpr lanemask GROUP1 = 0xF0F0F0F0F0F0F0F0ull;   // lanes with bit 2 set: the right half of the region
+        const bool in_group1 = (lane & 4) != 0;
+        // the next face of a lane group: the key of its first pending pixel / ring cell, or -2 (no key: -1 is "no face")
+        auto next_key = [&](lanemask group) {
+            const lanemask p0 = pend[0] & group, p1 = pend[1] & group, p2 = pend[2] & group, p3 = pend[3] & group;
+            const lanemask p4 = pend[4] & group, p5 = pend[5] & group;
+            if (p0) return __builtin_amdgcn_readlane(key[0], __ffsll((long long)p0) - 1);
+            if (p1) return __builtin_amdgcn_readlane(key[1], __ffsll((long long)p1) - 1);
+            if (p2) return __builtin_amdgcn_readlane(key[2], __ffsll((long long)p2) - 1);
+            if (p3) return __builtin_amdgcn_readlane(key[3], __ffsll((long long)p3) - 1);
+            if (p4) return __builtin_amdgcn_readlane(lkey[0], __ffsll((long long)p4) - 1);
+            if (p5) return __builtin_amdgcn_readlane(lkey[1], __ffsll((long long)p5) - 1);
+            return -2;
+        };
         for (;;) {
-            int K;
-            if (pend[0]) K = __builtin_amdgcn_readlane(key[0], __ffsll((long long)pend[0]) - 1);
-            else if (pend[1]) K = __builtin_amdgcn_readlane(key[1], __ffsll((long long)pend[1]) - 1);
-            else if (pend[2]) K = __builtin_amdgcn_readlane(key[2], __ffsll((long long)pend[2]) - 1);
-            else if (pend[3]) K = __builtin_amdgcn_readlane(key[3], __ffsll((long long)pend[3]) - 1);
-            else if (pend[4]) K = __builtin_amdgcn_readlane(lkey[0], __ffsll((long long)pend[4]) - 1);
-            else if (pend[5]) K = __builtin_amdgcn_readlane(lkey[1], __ffsll((long long)pend[5]) - 1);
-            else break;
-            // the face's vertex indices (a wave-uniform address: requested now, needed after the reduction)
-            const int32_t* fk = faces + (size_t)(uint32_t)K * 3;
-            const int v0 = fk[0], v1 = fk[1], v2 = fk[2];
+            // one face per lane group and iteration: the two halves of the region see different faces, so the wave
+            // needs about as many iterations as the busier half has faces
+            const int K0 = next_key(~GROUP1), K1 = next_key(GROUP1);
+            if (K0 == -2 && K1 == -2) break;
+            const int K = in_group1 ? K1 : K0;
+            // the faces' vertex indices (wave-uniform addresses: requested now, needed after the reduction)
+            const int32_t* fk0 = faces + (size_t)(uint32_t)max(K0, 0) * 3;
+            const int32_t* fk1 = faces + (size_t)(uint32_t)max(K1, 0) * 3;
+            const int a0 = fk0[0], a1 = fk0[1], a2 = fk0[2], b0 = fk1[0], b1 = fk1[1], b2 = fk1[2];
             float2v accp[NR / 2];
 #pragma unroll
             for (int i = NV / 2; i < NR / 2; ++i) accp[i] = float2v{0.f, 0.f};
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const bool m = lkey[e] == K;
-                const unsigned long long mm = __builtin_amdgcn_ballot_w64(m);
+                const lanemask mm = __builtin_amdgcn_ballot_w64(m);
                 if (mm != 0ull) {
                     pend[4 + e] &= ~mm;
 #pragma unroll
@@ -478,8 +490,9 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 #pragma unroll
             for (int i = 0; i < NR / 2; ++i) { acc[2 * i] = accp[i].x; acc[2 * i + 1] = accp[i].y; }
             const float total = wave_reduce_scatter<NR>(acc, lane);
-            const int vsel = role_k == 0 ? v0 : (role_k == 1 ? v1 : v2);
-            if (role_valid && total != 0.f)
+            const int vsel0 = role_k == 0 ? a0 : (role_k == 1 ? a1 : a2), vsel1 = role_k == 0 ? b0 : (role_k == 1 ? b1 : b2);
+            const int vsel = in_group1 ? vsel1 : vsel0;
+            if (role_valid && total != 0.f)   // (a group without a face this iteration has all-zero totals)
                 atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(role_base) + (size_t)((uint32_t)vsel * role_stride)), total);
         }
     };
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         long long* o = g_trace_grad + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16;
         for (int i = 0; i < 12; ++i) o[i] = i < tr_n ? tr_t[i] : 0;
         o[12] = tr_c[0]; o[13] = tr_c[1];
-        o[14] = tr_wall0; o[15] = ((long long)wall_clock64() << 20) | (long long)(__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4 /* HW_REG_HW_ID */) & 0xFFFFF);
+        o[14] = tr_wall0; o[15] = (((long long)wall_clock64() - tr_wall0) << 20) | (long long)(__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4 /* HW_REG_HW_ID */) & 0xFFFFF);
     }
 #endif
 }

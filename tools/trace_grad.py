@@ -32,7 +32,7 @@ print('  dilated pairs listed per wave: mean %.1f max %d;  face-loop iterations 
 print('  face loop clocks per iteration: %.0f' % (d[:, 6].sum() / max(1, a[:, 13].sum())))
 print('  kernel span (first start .. last end, clocks; not comparable across CUs): %d' % (tt[:, 7].max() - tt[:, 0].min()))
 
-w0 = a[:, 14].astype(np.float64); w1 = (a[:, 15] >> 20).astype(np.float64)
+w0 = a[:, 14].astype(np.float64); w1 = w0 + (a[:, 15] >> 20).astype(np.float64)
 t0 = w0.min()
 print('  wall clock (100 MHz): wave starts %.2f .. %.2f us after the first; ends %.2f .. %.2f us; wave duration mean %.2f us' % (
     0.0, (w0.max() - t0) / 100.0, (w1.min() - t0) / 100.0, (w1.max() - t0) / 100.0, ((w1 - w0).mean()) / 100.0))
@@ -61,3 +61,19 @@ if len(wg_it) == 1024:
     cu_it = wg_it.reshape(4, 256).sum(0); cu_end = wg_end.reshape(4, 256).max(0)
     print('  per CU (blocks b, b+256, b+512, b+768): iterations mean %.0f max %.0f (+%.0f%%); slowest workgroup mean %.0f max %.0f; corr %.2f' % (
         cu_it.mean(), cu_it.max(), 100 * (cu_it.max() / cu_it.mean() - 1), cu_end.mean(), cu_end.max(), np.corrcoef(cu_end, cu_it)[0, 1]))
+
+# which phase makes a wave slow, and when (global clock) the waves end
+for i, n in enumerate(names):
+    print('  corr(total, %-24s) = %5.2f   p90 - p50 of the phase: %6.0f clocks' % (n, np.corrcoef(tot, d[:, i])[0, 1], np.percentile(d[:, i], 90) - np.percentile(d[:, i], 50)))
+en = (w1 - t0) / 100.0
+print('  end times (us after the first wave start): p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f' % tuple(np.percentile(en, [10, 50, 90, 99, 100])))
+wg_last = en.reshape(-1, 4).max(1)
+if len(wg_last) == 1024:
+    tiles_x = (W + 31) // 32
+    # position of the tile inside its XCD band (xcd_tile: XCD x owns tiles x * 128 .. x * 128 + 127 = four tile rows)
+    b = np.arange(1024); tile = (b & 7) * 128 + (b >> 3)
+    row_in_band = (tile // tiles_x) % 4
+    for r in range(4):
+        print('    tile row %d of the XCD band: workgroup end mean %.2f us' % (r, wg_last[row_in_band == r].mean()))
+    order = np.argsort(wg_last)[-12:]
+    print('    last workgroups (block, tile, end us, iterations):', [(int(x), int(tile[x]), round(float(wg_last[x]), 2), int(wg_it[x])) for x in order])
