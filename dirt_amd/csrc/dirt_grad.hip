@@ -314,16 +314,21 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     float2* const inbox = &s_inbox[wave][0];
     const int my_cell = (ry + 1) * IS + 4 * sx + 2;   // the strip's first pixel in the inbox
 
-    // ---- staging: loads of the pass's channels of the pixels tile (+halo), edge clamped (at(), :113-124).  Item i is
-    //      row i / 36, column x0 - 1 + i % 36; five items per thread, every load issued before any use ----
-    constexpr int PITEMS = (PR * PS + GTHREADS - 1) / GTHREADS;
+    // ---- staging: loads of the pass's channels of the pixels tile (+halo), edge clamped (at(), :113-124).  A thread
+    //      keeps one column (x0 - 1 + tid % 36) and takes rows tid / 36, + 7, + 14, ... of the 34: the column clamp and
+    //      the LDS address are computed once, an item costs a row clamp and one multiply-add.  Five items per thread,
+    //      every load issued before any use (threads 252 .. 255 idle). ----
+    constexpr int PROWS = GTHREADS / PS;                         // rows per sweep: 7
+    constexpr int PITEMS = (PR + PROWS - 1) / PROWS;             // 5
+    const int st_row = tid / PS, st_ci = tid - st_row * PS;      // (as unsigned small numbers: a multiply-high, once)
+    const bool st_on = tid < PROWS * PS;
+    const uint32_t st_xoff = (uint32_t)min(max(x0 - 1 + st_ci, 0), W - 1) * pixel_bytes;
+    const uint32_t row_bytes = (uint32_t)W * pixel_bytes;
     auto stage_load = [&](int nch, float (&v)[PITEMS][PC]) {
 #pragma unroll
         for (int k = 0; k < PITEMS; ++k) {
-            const int i = min(tid + k * GTHREADS, PR * PS - 1);
-            const int row = i / PS, ci = i - row * PS;
-            const int cy = min(max(y0 - 1 + row, 0), H - 1), cx = min(max(x0 - 1 + ci, 0), W - 1);
-            const uint32_t off = (uint32_t)((cy - row0) * W + cx) * pixel_bytes;
+            const int cy = min(max(y0 - 1 + st_row + PROWS * k, 0), H - 1);
+            const uint32_t off = (uint32_t)(cy - row0) * row_bytes + st_xoff;
             if (nch == 4 && (C & 3) == 0 && aligned16) {
                 const float4 q = ld_off<float4>(pixels_t, off);
                 v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
@@ -337,12 +342,11 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         }
     };
     auto stage_store = [&](int nch, const float (&v)[PITEMS][PC]) {
+        const int col = st_ci == 0 ? PS - 1 : st_ci - 1;
 #pragma unroll
         for (int k = 0; k < PITEMS; ++k) {
-            const int i = tid + k * GTHREADS;
-            if (i >= PR * PS) continue;
-            const int row = i / PS, ci = i - row * PS;
-            const int col = ci == 0 ? PS - 1 : ci - 1;
+            const int row = st_row + PROWS * k;
+            if (!st_on || row >= PR) continue;
 #pragma unroll
             for (int ch = 0; ch < NPLANES; ++ch)
                 if (ch < nch) s_pix[ch][row][col] = v[k][ch];
@@ -362,21 +366,22 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     float stage_v[PITEMS][PC];
     stage_load(CSPEC, stage_v);
     {
-        constexpr int VITEMS = (PR * PR + GTHREADS - 1) / GTHREADS;
+        // (the same sweep: column x0 - 1 + tid % 34, rows tid / 34, + 7, ...; threads 238 .. 255 idle)
+        constexpr int VITEMS = (PR + PROWS - 1) / PROWS;
+        const int v_row = tid / PR, v_ci = tid - v_row * PR;
+        const bool v_on = tid < PROWS * PR;
+        const uint32_t v_xoff = (uint32_t)min(max(x0 - 1 + v_ci, 0), W - 1) * 8u;
         float2 rec[VITEMS];
 #pragma unroll
         for (int k = 0; k < VITEMS; ++k) {
-            const int i = min(tid + k * GTHREADS, PR * PR - 1);
-            const int row = i / PR, ci = i - row * PR;
-            const int cy = min(max(y0 - 1 + row, 0), H - 1), cx = min(max(x0 - 1 + ci, 0), W - 1);
-            rec[k] = ld_off<float2>(state_a, (uint32_t)((cy - row0) * W + cx) * 8u);
+            const int cy = min(max(y0 - 1 + v_row + PROWS * k, 0), H - 1);
+            rec[k] = ld_off<float2>(state_a, (uint32_t)(cy - row0) * ((uint32_t)W * 8u) + v_xoff);
         }
 #pragma unroll
         for (int k = 0; k < VITEMS; ++k) {
-            const int i = tid + k * GTHREADS;
-            if (i >= PR * PR) continue;
-            const int row = i / PR, ci = i - row * PR;
-            s_vw[row][ci + 1] = rec[k];
+            const int row = v_row + PROWS * k;
+            if (!v_on || row >= PR) continue;
+            s_vw[row][v_ci + 1] = rec[k];
         }
     }
     // own barycentrics b0, b1

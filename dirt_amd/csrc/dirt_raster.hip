@@ -319,6 +319,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
 
 #ifdef DIRT_TRACE
     long long tr_t[8]; int tr_n = 0;
+    const long long tr_wall0 = wall_clock64();
 #define TRACE_MARK() do { if (tr_n < 8) tr_t[tr_n++] = clock64(); } while (0)
     long long tr_acc[4] = {0, 0, 0, 0}, tr_last = 0; int tr_cnt = 0;
 #define TRACE_ACC(i) do { long long now_ = clock64(); if ((i) > 0) tr_acc[i] += now_ - tr_last; tr_last = now_; } while (0)
@@ -600,6 +601,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
         long long* o = g_trace_buf + ((size_t)blockIdx.x * 4 + wave) * 16;
         for (int i = 0; i < 8; ++i) o[i] = i < tr_n ? tr_t[i] : 0;
         o[8] = tr_acc[1]; o[9] = tr_acc[2]; o[10] = tr_acc[3]; o[11] = tr_cnt;
+        o[12] = tr_wall0; o[13] = (long long)wall_clock64() - tr_wall0; o[14] = blockIdx.x;
     }
 #endif
 }

@@ -31,3 +31,17 @@ for n, col in (('  of candidates: staging', 8), ('  of candidates: loop', 9), ('
 tot = tt[:, 6] - tt[:, 0]
 print('  %-34s %9.0f %9.0f %9.0f' % ('total', tot.mean(), np.median(tot), tot.max()))
 print('  candidates visited per wave: mean %.1f max %d' % (a[:, 11].mean(), a[:, 11].max()))
+
+# global clock (100 MHz): when the waves start and end, and how that goes with the order in which a CU got its workgroups
+w0 = a[:, 12].astype(np.float64); w1 = w0 + a[:, 13].astype(np.float64); t0 = w0.min()
+st, en = (w0 - t0) / 100.0, (w1 - t0) / 100.0
+print('  wave starts (us): p50 %.2f p99 %.2f max %.2f;  ends: p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f;  mean duration %.2f us' % (
+    *np.percentile(st, [50, 99, 100]), *np.percentile(en, [10, 50, 90, 99, 100]), (en - st).mean()))
+print('  s_memtime clocks per us of global clock: %.0f' % (tot.sum() / (en - st).sum()))
+blk = a[:, 14].astype(np.int64)
+if blk.max() == 1023:
+    for r in range(4):
+        sel = (blk >> 3) // 32 == r
+        print('    workgroups %d of a CU (blocks with (b / 8) / 32 == %d): end mean %.2f us, candidates visited per wave %.1f' % (r + 1, r, en[sel].mean(), a[sel, 11].mean()))
+for i, n in enumerate(names):
+    print('  corr(total, %-32s) = %5.2f' % (n, np.corrcoef(tot, d[:, i])[0, 1]))
