@@ -48,7 +48,7 @@ def main():
     shutil.copy(os.path.join(src, 'trace', 'trace_kernel_stats.csv'), os.path.join(dst, tag + '_kernel_stats.csv'))
     buf = io.StringIO()
     with redirect_stdout(buf):
-        sys.argv = ['pmc_summary'] + [os.path.join(src, d) for d in ('trace', 'pmc_sq', 'pmc_lds', 'pmc_fetch', 'pmc_write', 'pmc_l2')]
+        sys.argv = ['pmc_summary'] + [os.path.join(src, d) for d in ('trace', 'pmc_sq', 'pmc_act', 'pmc_lds', 'pmc_fetch', 'pmc_write', 'pmc_l2') if os.path.isdir(os.path.join(src, d))]
         pmc_summary.main()
     open(os.path.join(dst, tag + '_pmc.txt'), 'w').write(buf.getvalue().replace(ROOT + '/', ''))
     line = [l for l in open(os.path.join(src, 'bench.json')).read().splitlines() if l.startswith('{')][-1]
@@ -63,7 +63,10 @@ def main():
         fetch = counter(glob.glob(os.path.join(src, 'pmc_fetch' + suffix, '*counter_collection.csv'))[0], 'FETCH_SIZE')
         write = counter(glob.glob(os.path.join(src, 'pmc_write' + suffix, '*counter_collection.csv'))[0], 'WRITE_SIZE')
         # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
-        return {slot(k): int(2 * fetch[k] * 1024 + write.get(k, 0) * 1024) for k in fetch}
+        out = collections.defaultdict(int)   # launches of one slot (the per-shape gradient launches of many-channel images) add up
+        for k in fetch:
+            out[slot(k)] += int(2 * fetch[k] * 1024 + write.get(k, 0) * 1024)
+        return dict(out)
 
     traffic = traffic_of('')
     path = os.path.join(dst, 'pmc_traffic.json')
@@ -78,6 +81,16 @@ def main():
     allt['_note'] = ('HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes); the factor 2 is the gfx950 FETCH_SIZE '
                      'correction of MI355X_MICROARCH.md (calibrated there for wide coalesced reads; narrower accesses are uncalibrated)')
     json.dump(allt, open(path, 'w'), indent=1)
+    # the bench lines were written before this summary existed: give them the traffic figures of this collection
+    for f in glob.glob(os.path.join(dst, tag + '_bench*.json')):
+        d = json.load(open(f))
+        cfg = d['config']['workload'].split(':')[0]
+        spg = d['config'].get('scenes_per_gpu', 1)
+        t = allt.get(cfg, {}).get(d['roofline']['kernel'])
+        d['roofline']['traffic'] = t * spg if t is not None else None
+        d['roofline']['traffic_source'] = ('profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of one scene of this workload%s, '
+                                           'not measured in the bench run' % (tag, ' x %d scenes per launch' % spg if spg > 1 else '')) if t is not None else None
+        json.dump(d, open(f, 'w'), indent=1)
     print(json.dumps(traffic, indent=1))
 
 
