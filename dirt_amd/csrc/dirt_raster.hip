@@ -389,6 +389,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
         TRACE_MARK();  // 2: cleared, barrier
         // ---- scan: this thread's runs, four entries per trip ----
         bool full = false;
+        uint32_t touch = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             while (run_pos[k] < run_count[k] && !full) {
@@ -412,12 +413,18 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
                         for (int by = by0; by <= by1; ++by) mask |= rowbits << (BT * by);
                         s_face[slot] = en[i].face;
                         s_mask[slot] = (uint16_t)mask;
+                        // the staging pass reads this face's set-up record (one 128-byte line, written by another XCD's
+                        // set-up workgroup) after the list barrier: touch it now, so that it is on its way to this
+                        // XCD's L2 while the list is still being built.  The loaded word is never used; `touch` stays
+                        // live until the wait below, so that its register is not reused while loads are in flight.
+                        asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(recs + en[i].face));
                     }
                     ++run_pos[k];
                 }
             }
         }
         TRACE_MARK();  // 3: appended
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch));
         __syncthreads();
         const int n = (int)min(s_count, (uint32_t)LIST_CAP);
         if (round != 0) lds_records = false;
