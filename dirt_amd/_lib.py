@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DIRT_AMD_LIBRARY') or os.path.join(_HERE, 'libdirt_hip.so')  # override: instrumented builds (tools/)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FLAG_Q1_INTENDED = 1
 FLAG_KEEP_STATE = 2
@@ -66,7 +66,8 @@ def load():
     lib.dirt_rasterise_backward.restype = i
     lib.dirt_rasterise_visibility.argtypes = [fp, ip, ip, i, i, i, i, i, vp, sz, u, vp]
     lib.dirt_rasterise_visibility.restype = i
-    lib.dirt_state_grad_buffers.argtypes = [vp, sz, i, i, i, i, i, i, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    lib.dirt_state_grad_buffers.argtypes = [vp, sz, i, i, i, i, i, i, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                            ctypes.POINTER(i), ctypes.POINTER(i)]
     lib.dirt_state_grad_buffers.restype = i
     lib.dirt_profile_count.restype = i
     lib.dirt_profile_name.argtypes = [i]

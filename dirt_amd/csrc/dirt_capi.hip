@@ -88,10 +88,12 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
     size_t recs_off, boxes_off, cells_off, entries_off, state_a_off, state_b_off, gv_off, gvc_off, total;
+    bool interleaved;   // the two gradient accumulators share rows of 8 floats
 };
 
 // Layout: [FaceRec x B*F | FaceBox x B*F | chunk x bin directory | per-chunk BinEntry segments (5 per face) |
-//          float2 per-pixel state {clip_w, face} x B*H*W | float2 {b0, b1} x B*H*W | float grad_vertices x B*V*4 |
+//          float2 per-pixel state {clip_w, face} x B*H*W | float2 {b0, b1} x B*H*W | gradient accumulators:
+//          float x B*V*8 (C <= 4: a vertex's position and colour gradients in one row), or float grad_vertices x B*V*4 |
 //          float grad_vertex_colors x B*V*C]
 Workspace carve(int B, int V, int F, int H, int W, int C)
 {
@@ -105,9 +107,16 @@ Workspace carve(int B, int V, int F, int H, int W, int C)
     w.entries_off = off; off = align_up(off + (size_t)B * nchunk * 5 * (size_t)chunk_faces * sizeof(dirt::BinEntry), 256);
     w.state_a_off = off; off = align_up(off + (size_t)B * H * W * sizeof(float2), 256);
     w.state_b_off = off; off = align_up(off + (size_t)B * H * W * sizeof(float2), 256);
-    // gradient accumulators of the backward pass, pre-cleared by a KEEP_STATE forward (dirt_state_grad_buffers)
-    w.gv_off = off;      off = align_up(off + (size_t)B * V * 4 * sizeof(float), 256);
-    w.gvc_off = off;     off = align_up(off + (size_t)B * V * C * sizeof(float), 256);
+    // gradient accumulators of the backward pass, pre-cleared by a KEEP_STATE forward (dirt_state_grad_buffers):
+    // C <= 4: interleaved, one row {x, y, z, w, c0 .. c3} of 8 floats per vertex; else [B,V,4] and [B,V,C]
+    w.interleaved = C <= 4;
+    if (w.interleaved) {
+        w.gv_off = off;  w.gvc_off = off + 4 * sizeof(float);
+        off = align_up(off + (size_t)B * V * 8 * sizeof(float), 256);
+    } else {
+        w.gv_off = off;  off = align_up(off + (size_t)B * V * 4 * sizeof(float), 256);
+        w.gvc_off = off; off = align_up(off + (size_t)B * V * C * sizeof(float), 256);
+    }
     w.total = off + 256;
     return w;
 }
@@ -242,8 +251,12 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
     dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
     if (flags & DIRT_FLAG_KEEP_STATE) {  // pre-clear the backward pass's accumulators (dirt_state_grad_buffers)
-        g.zero_b = c.gv;  g.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
-        g.zero_c = c.gvc; g.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
+        if (w.interleaved) {
+            g.zero_b = c.gv;  g.zero_b_bytes = sizeof(float) * (size_t)B * V * 8;
+        } else {
+            g.zero_b = c.gv;  g.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
+            g.zero_c = c.gvc; g.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
+        }
     }
     {
         Scope sc(prof, SLOT_GEOMETRY, stream);
@@ -319,10 +332,12 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
     // the cudaMemsetAsync x4 of csrc/rasterise_grad_egl.cu:244-250: grad_vertices / grad_vertex_colors
     // are cleared by one launch; grad_background and debug_thingy are fully written by the gradient
     // kernel instead
+    // the caller's outputs are dense unless they are the state's own accumulators (dirt_state_grad_buffers)
+    const bool state_outputs = (flags & DIRT_FLAG_REUSE_STATE) && grad_vertices == c.gv && grad_vertex_colors == c.gvc;
     if (flags & DIRT_FLAG_REUSE_STATE) {
         // records + visibility were left in this workspace by the forward pass; so were cleared gradient
-        // accumulators: if the caller's outputs ARE those (dirt_state_grad_buffers) nothing is left to do
-        if (!(grad_vertices == c.gv && grad_vertex_colors == c.gvc)) {
+        // accumulators: if the caller's outputs ARE those nothing is left to do
+        if (!state_outputs) {
             Scope sc(prof, SLOT_GEOMETRY, stream);
             HIP_TRY(who, dirt::launch_zero(grad_vertices, sizeof(float) * (size_t)B * V * 4, grad_vertex_colors,
                                            sizeof(float) * (size_t)B * V * C, stream));
@@ -347,6 +362,8 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
     gp.pixels = pixels; gp.grad_pixels = grad_pixels;
     gp.grad_background = grad_background; gp.grad_vertices = grad_vertices;
     gp.grad_vertex_colors = grad_vertex_colors; gp.debug_thingy = debug_thingy;
+    gp.gv_stride = state_outputs && w.interleaved ? 8 : 4;
+    gp.gvc_stride = state_outputs && w.interleaved ? 8 : C;
     gp.B = B; gp.V = V; gp.F = F; gp.H = H; gp.W = W; gp.C = C; gp.flags = flags;
     {
         Scope sc(prof, SLOT_GRAD, stream);
@@ -357,7 +374,8 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
 }
 
 int dirt_state_grad_buffers(void* workspace, size_t workspace_bytes, int B, int V, int F, int H, int W, int C,
-                            float** grad_vertices, float** grad_vertex_colors)
+                            float** grad_vertices, float** grad_vertex_colors, int* grad_vertices_row_stride,
+                            int* grad_vertex_colors_row_stride)
 {
     const char* who = "dirt_state_grad_buffers";
     int rc = check_sizes(who, B, V, F, H, W, C);
@@ -368,6 +386,8 @@ int dirt_state_grad_buffers(void* workspace, size_t workspace_bytes, int B, int 
     const Carved c = carved(workspace, w);
     if (grad_vertices) *grad_vertices = c.gv;
     if (grad_vertex_colors) *grad_vertex_colors = c.gvc;
+    if (grad_vertices_row_stride) *grad_vertices_row_stride = w.interleaved ? 8 : 4;
+    if (grad_vertex_colors_row_stride) *grad_vertex_colors_row_stride = w.interleaved ? 8 : C;
     return DIRT_OK;
 }
 

@@ -28,6 +28,7 @@
 // Variable names in the per-pixel arithmetic follow the CUDA source.
 #include "dirt_device.h"
 #include "dirt_launch.h"
+#include "dirt_reduce.h"
 #include "../../include/dirt_hip.h"
 #include <type_traits>
 #include <cstdlib>
@@ -76,89 +77,16 @@ __device__ __forceinline__ float2v pk_mul_scalar(float s, float2v b)
 #pragma clang diagnostic pop
 
 constexpr int GT = 32;                  // tile side (pixels)
-constexpr int GTHREADS = 256;           // 4 waves: wave w owns rows 8w .. 8w+7, lane l the strip x = 4 * (l & 7) .. +3 of row l >> 3
+constexpr int GTHREADS = 256;           // 4 waves: wave w owns rows 8w .. 8w+7; a DPP row of 16 lanes owns an 8 x 8 block of them
+                                        // (block l >> 4), lane l the strip x = 8 * (l >> 4) + 4 * (l & 1) .. +3 of row (l >> 1) & 7
 constexpr int PR = GT + 2;              // staged rows: y0-1 .. y0+32
-constexpr int PS = 36;                  // plane row stride (floats): column (x - x0) for x0 .. x0+34, column 35 holds x0-1
+constexpr int PS = 36;                  // plane row stride (floats): column (x - x0) + 1 for x0-1 .. x0+34, so that a strip's taps start
+                                        // (with the column left of it) at a 16-byte boundary
 constexpr int VS = 36;                  // state tile row stride (float2): column (x - x0) + 2, so that strips are 16-byte aligned
 constexpr int PC = 4;                   // channels per pass: whole channel groups that fit in 4 channels
 constexpr int IS = 34;                  // inbox row stride (float2 cells): cell (ty + 1) * 34 + tx + 2 for ty in -1..8, tx in -1..32
 constexpr int ICELLS = 10 * IS + 4;     // ... of a wave's 32 x 8 region and the one-pixel ring around it (a multiple of 2: 16-byte cells pairs)
 constexpr int RING = 2 * 34 + 2 * 8;    // ring cells: what the wave's pixels sent to pixels of other waves
-
-// Reduce N (16 or 24) per-lane values over the lanes of the wave, separately for its two lane GROUPS (lane bit 2: the
-// left and the right 16 x 8 pixels of the wave's region, see the face loop): a transposing butterfly.  At every level a
-// lane is paired with the lane that differs in one lane bit, and value i with value i + (half of what is left): the lane
-// keeps one of the two values, sends the other to its partner and adds what it receives, so that registers halve while
-// lanes specialise.  Inside a DPP row of 16 lanes: bit 3 (row_ror:8; the "upper" lanes are whole DPP banks, so the pair
-// takes two bank-masked DPP adds and no selects), bit 1 and bit 0 (quad permutations: two selects and a DPP add); then
-// v_permlane32_swap and v_permlane16_swap add the four rows.  ~60 instructions for 24 values x 2 groups (plain DPP
-// reductions of every value would be several hundred).  The total of value
-//     v = i(row) + b0 * N/8 + b1 * N/4 + b3 * N/2        (b_k: bit k of the lane;  i: N = 24: rows 0, 2, 1 -> 0, 1, 2;
-//                                                          N = 16: rows 0, 2 -> 0, 1; other rows hold copies)
-// over the lanes of group b2 ends up in that lane (reduce_value_of_lane() below).
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v)
-{
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-
-template <int CTRL>
-__device__ __forceinline__ float pack_pair(float lo, float hi, bool upper)
-{
-    const float keep = upper ? hi : lo, send = upper ? lo : hi;
-    return keep + dpp_mov<CTRL>(send);
-}
-
-// The same for the level whose "upper" lanes are whole DPP banks (lanes 8-15 of a row: banks 2, 3): lo + partner's lo
-// everywhere, then hi + partner's hi written to the upper banks only -- two instructions, no selects.  (Written as
-// assembly: the bank-masked form of a DPP add has no builtin.  A DPP operand written by the preceding VALU instruction
-// needs two wait states: the leading s_nop.)
-__device__ __forceinline__ float pack_pair_bit3(float lo, float hi)
-{
-    float r;
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
-        : "=&v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-
-template <int N>
-__device__ __forceinline__ float wave_reduce_scatter(const float* val, int lane)
-{
-    static_assert(N == 16 || N == 24, "16 or 24 values");
-    constexpr int QUAD_XOR2 = 0x4E /* [2,3,0,1] */, QUAD_XOR1 = 0xB1 /* [1,0,3,2] */;
-    const bool u2 = (lane & 2) != 0, u1 = (lane & 1) != 0;
-    float a[N / 2], b[N / 4], c[N / 8];
-#pragma unroll
-    for (int i = 0; i < N / 2; ++i) a[i] = pack_pair_bit3(val[i], val[i + N / 2]);
-#pragma unroll
-    for (int i = 0; i < N / 4; ++i) b[i] = pack_pair<QUAD_XOR2>(a[i], a[i + N / 4], u2);
-#pragma unroll
-    for (int i = 0; i < N / 8; ++i) c[i] = pack_pair<QUAD_XOR1>(b[i], b[i + N / 8], u1);
-    // the four rows: halves, then rows of a half
-    auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(c[1]), false, false);
-    const float t0 = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);   // lanes 0-31: c[0] (rows 0+2 | 1+3), lanes 32-63: c[1]
-    float t1 = t0;
-    if (N == 24) {
-        auto s32b = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[2]), __float_as_uint(c[2]), false, false);
-        t1 = __uint_as_float(s32b[0]) + __uint_as_float(s32b[1]);         // every lane: c[2], the two halves added
-    }
-    auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(t0), __float_as_uint(t1), false, false);
-    return __uint_as_float(s16[0]) + __uint_as_float(s16[1]);             // rows 0, 2: t0's totals; rows 1, 3: t1's
-}
-
-// The value whose total (over the lane's group) wave_reduce_scatter<N> leaves in `lane`, or -1.
-template <int N>
-__device__ __forceinline__ int reduce_value_of_lane(int lane)
-{
-    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b3 = (lane >> 3) & 1, row = lane >> 4;
-    int i = -1;
-    if (row == 0) i = 0;
-    if (row == 2) i = 1;
-    if (N == 24 && row == 1) i = 2;
-    return i < 0 ? -1 : i + b0 * (N / 8) + b1 * (N / 4) + b3 * (N / 2);
-}
 
 // Quirk Q1 at the right image border: for the pixels of a strip (first column xs, row y) flagged in `which`, the
 // aliased "channels" 1, 2 of 1-channel group c -- elements (pixel + 1, + 2) of the flattened [B,H,W,1] slice -- lie in
@@ -291,15 +219,19 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     const float* __restrict__ gpix_t = p.grad_pixels + origin * C + cbase;
     float* __restrict__ gbk_t = p.grad_background + origin * C + cbase;
     const int32_t* __restrict__ faces = p.faces + (p.shared_faces ? (size_t)0 : (size_t)iib * p.F * 3);
-    float* __restrict__ grad_vertices = p.grad_vertices + (size_t)iib * p.V * 4;
-    float* __restrict__ grad_vertex_colors = p.grad_vertex_colors + (size_t)iib * p.V * C + cbase;
+    // (rows of p.gv_stride / p.gvc_stride floats: 4 and C for dense tensors; both 8, the colours 16 bytes behind the
+    // positions, for the state's interleaved accumulators, where a vertex's seven values share one 32-byte row)
+    float* __restrict__ grad_vertices = p.grad_vertices + (size_t)iib * p.V * p.gv_stride;
+    float* __restrict__ grad_vertex_colors = p.grad_vertex_colors + (size_t)iib * p.V * p.gvc_stride + cbase;
+    const uint32_t gv_row_bytes = 4u * (uint32_t)p.gv_stride, gvc_row_bytes = 4u * (uint32_t)p.gvc_stride;
     const uint32_t pixel_bytes = 4u * (uint32_t)C;
 
     const bool q1_intended = (p.flags & DIRT_FLAG_Q1_INTENDED) != 0;
     const float width_f = (float)W, height_f = (float)H;
 
     // ---- this lane's strip ----
-    const int sx = lane & 7, ry = lane >> 3;
+    const int blk = lane >> 4;                  // the lane's DPP row = its 8 x 8 block of the wave's region
+    const int sx = 2 * blk + (lane & 1), ry = (lane >> 1) & 7;
     const int xs = x0 + 4 * sx;                 // first pixel of the strip
     const int y = y0 + 8 * wave + ry;           // tensor row (top row first)
     const int hr = 8 * wave + ry + 1;           // its row in the halo'd tile
@@ -315,8 +247,8 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     const int my_cell = (ry + 1) * IS + 4 * sx + 2;   // the strip's first pixel in the inbox
 
     // ---- staging: loads of the pass's channels of the pixels tile (+halo), edge clamped (at(), :113-124).  A thread
-    //      keeps one column (x0 - 1 + tid % 36) and takes rows tid / 36, + 7, + 14, ... of the 34: the column clamp and
-    //      the LDS address are computed once, an item costs a row clamp and one multiply-add.  Five items per thread,
+    //      keeps one column (x0 - 1 + tid % 36, plane column tid % 36) and takes rows tid / 36, + 7, + 14, ... of the 34: the
+    //      column clamp and the LDS address are computed once, an item costs a row clamp and one multiply-add.  Five items per thread,
     //      every load issued before any use (threads 252 .. 255 idle). ----
     constexpr int PROWS = GTHREADS / PS;                         // rows per sweep: 7
     constexpr int PITEMS = (PR + PROWS - 1) / PROWS;             // 5
@@ -342,7 +274,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         }
     };
     auto stage_store = [&](int nch, const float (&v)[PITEMS][PC]) {
-        const int col = st_ci == 0 ? PS - 1 : st_ci - 1;
+        const int col = st_ci;
 #pragma unroll
         for (int k = 0; k < PITEMS; ++k) {
             const int row = st_row + PROWS * k;
@@ -399,75 +331,81 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { fxy[j][0] = 0.f; fxy[j][1] = 0.f; }
 
-    // ---- the face loop.  The wave walks the distinct faces among its pixels (key[j], -1 = none) and among the ring
-    //      cells it holds (lkey): per face every lane forms its masked partial sums -- per vertex k the S values
-    //      b_k * (fx, fy, fw, g_0 .. g_NCHV-1 [, 0]) (S = 3 + NCHV rounded up to even), as S / 2 packed pairs: one
-    //      v_pk_fma_f32 per pair and pixel -- the 3 S sums are reduced across the wave (wave_reduce_scatter) and one
-    //      atomic instruction adds the totals to the face's three vertices. ----
+    // ---- the face loop.  Every DPP row of the wave (16 lanes = an 8 x 8 pixel block) walks the distinct faces among its
+    //      pixels (key[j], -1 = none) and among the ring cells its lanes hold (lkey), all four rows at once: an iteration
+    //      takes one face per row.  Per face every lane forms its masked partial sums -- per vertex k the S values
+    //      b_k * (g_0 .. g_NCHV-1, fx, fy, fw) (S = 3 + NCHV rounded up to even; order below), as S / 2 packed pairs: one
+    //      v_pk_fma_f32 per pair and pixel -- the 3 S sums are reduced over the lanes of the row (row_reduce_scatter,
+    //      dirt_reduce.h: the totals of the row's face land in different lanes of the row) and at most two atomic
+    //      instructions add the four faces' totals to their vertices.  A block sees ~3 faces where the 16 x 8 half
+    //      regions of the two-group version saw ~6. ----
     auto face_loop = [&](auto nchv_tag, const auto& g, const int (&key)[4], const bool (&covered)[4],
                          const float (&fpos)[4][3], const int (&lkey)[2], const float (&lb)[2][3], const float (&lf)[2][3]) {
         constexpr int NCHV = decltype(nchv_tag)::value;
         constexpr int S = (3 + NCHV + 1) & ~1;      // values per vertex (padded to whole pairs)
         constexpr int HP = S / 2;                   // ... as pairs
         constexpr int NV = 3 * S;                   // values per face
-        constexpr int NR = NV <= 16 ? 16 : 24;      // ... padded to what the wave reduction takes
+        constexpr int NR = NV <= 16 ? 16 : 24;      // ... padded to what the row reduction takes
         static_assert(NV <= NR, "");
-        // this lane's role: it adds value role_v of the face (reduce_value_of_lane): vertex role_v / S, component
-        // c = role_v % S: c < 3: (x, y, w) of grad_vertices; else colour c - 3
-        const int role_v = reduce_value_of_lane<NR>(lane);
-        const int role_k = role_v >= 0 ? role_v / S : 0, role_c = role_v >= 0 ? role_v % S : S;
-        const bool role_valid = role_v >= 0 && role_v < NV && role_c < 3 + NCHV;
-        const bool role_pos = role_c < 3;
-        float* const role_base = role_pos ? grad_vertices + (role_c == 2 ? 3 : role_c) : grad_vertex_colors + (role_c - 3);
-        const uint32_t role_stride = role_pos ? 16u : pixel_bytes;
+        // Order of a vertex's values: the colours first (they arrive as whole registers of the grad_pixels loads), then
+        // the position factors with (fx, fy) as one aligned pair: NCHV even: g.., fx, fy, fw, 0;  odd: g.., fw, fx, fy.
+        constexpr int IW = (NCHV & 1) ? NCHV : NCHV + 2, IX = (NCHV & 1) ? NCHV + 1 : NCHV, IY = IX + 1;
+        static_assert((IX & 1) == 0 && IY < S && IW < S, "");
+        // this lane's roles: it adds the row totals of values rv[0], rv[1] of the row's face (row_value_of_lane): vertex
+        // rv / S, component c = rv % S: c < NCHV: colour c; IX, IY, IW: (x, y, w) of grad_vertices
+        // (the two rows of a pair end up with the same totals -- see the end of an iteration -- so the even row sends d0's
+        // value and the odd row d1's: one atomic instruction per iteration)
+        int rv0, rv1;
+        row_value_of_lane<NR>(lane & 15, rv0, rv1);
+        const bool odd_row = (blk & 1) != 0;
+        const int role_v = odd_row ? rv1 : rv0;
+        const int role_c = role_v >= 0 ? role_v % S : S;
+        const int role_k = role_v >= 0 && role_v < NV ? role_v / S : 0;
+        const bool role_pos = role_c == IX || role_c == IY || role_c == IW;
+        const bool role_valid = role_v >= 0 && role_v < NV && (role_c < NCHV || role_pos);
+        float* const role_base = role_pos ? grad_vertices + (role_c == IW ? 3 : role_c - IX) : grad_vertex_colors + (role_c < NCHV ? role_c : 0);
+        const uint32_t role_stride = role_pos ? gv_row_bytes : gvc_row_bytes;
         // the factors of a pixel, in pairs
         float2v fp[4][HP];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float f[S];
-            f[0] = fpos[j][0]; f[1] = fpos[j][1]; f[2] = fpos[j][2];
 #pragma unroll
-            for (int c = 3; c < S; ++c) f[c] = c - 3 < NCHV ? g[j][c - 3 < NCHV ? c - 3 : 0] : 0.f;
+            for (int c = 0; c < S; ++c) f[c] = c < NCHV ? g[j][c < NCHV ? c : 0] : 0.f;
+            f[IX] = fpos[j][0]; f[IY] = fpos[j][1]; f[IW] = fpos[j][2];
 #pragma unroll
             for (int h = 0; h < HP; ++h) { fp[j][h].x = f[2 * h]; fp[j][h].y = f[2 * h + 1]; }
         }
-        // pending pixels / ring cells as wave-wide masks (scalar registers)
-        lanemask pend[6];
+        // pending faces: the keys of this lane's pixels / ring cells not yet added (NONE: none or done; "no face" is -1 = NONE)
+        constexpr uint32_t NONE = 0xFFFFFFFFu;
+        uint32_t pend[6];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pend[j] = __builtin_amdgcn_ballot_w64(covered[j]);
-        pend[4] = __builtin_amdgcn_ballot_w64(lkey[0] >= 0);
-        pend[5] = __builtin_amdgcn_ballot_w64(lkey[1] >= 0);
-        constexpr lanemask GROUP1 = 0xF0F0F0F0F0F0F0F0ull;   // lanes with bit 2 set: the right half of the region
-        const bool in_group1 = (lane & 4) != 0;
-        // the next face of a lane group: the key of its first pending pixel / ring cell, or -2 (no key: -1 is "no face")
-        auto next_key = [&](lanemask group) {
-            const lanemask p0 = pend[0] & group, p1 = pend[1] & group, p2 = pend[2] & group, p3 = pend[3] & group;
-            const lanemask p4 = pend[4] & group, p5 = pend[5] & group;
-            if (p0) return __builtin_amdgcn_readlane(key[0], __ffsll((long long)p0) - 1);
-            if (p1) return __builtin_amdgcn_readlane(key[1], __ffsll((long long)p1) - 1);
-            if (p2) return __builtin_amdgcn_readlane(key[2], __ffsll((long long)p2) - 1);
-            if (p3) return __builtin_amdgcn_readlane(key[3], __ffsll((long long)p3) - 1);
-            if (p4) return __builtin_amdgcn_readlane(lkey[0], __ffsll((long long)p4) - 1);
-            if (p5) return __builtin_amdgcn_readlane(lkey[1], __ffsll((long long)p5) - 1);
-            return -2;
-        };
+        for (int j = 0; j < 4; ++j) pend[j] = (uint32_t)key[j];
+        pend[4] = (uint32_t)lkey[0]; pend[5] = (uint32_t)lkey[1];
         for (;;) {
-            // one face per lane group and iteration: the two halves of the region see different faces, so the wave
-            // needs about as many iterations as the busier half has faces
-            const int K0 = next_key(~GROUP1), K1 = next_key(GROUP1);
-            if (K0 == -2 && K1 == -2) break;
-            const int K = in_group1 ? K1 : K0;
-            // the faces' vertex indices (wave-uniform addresses: requested now, needed after the reduction)
-            const int32_t* fk0 = faces + (size_t)(uint32_t)max(K0, 0) * 3;
-            const int32_t* fk1 = faces + (size_t)(uint32_t)max(K1, 0) * 3;
-            const int a0 = fk0[0], a1 = fk0[1], a2 = fk0[2], b0 = fk1[0], b1 = fk1[1], b2 = fk1[2];
+            // the row's next face: the smallest pending key of its 16 lanes (an all-lanes minimum by four DPP rotations)
+            uint32_t K = min(min(min(pend[0], pend[1]), min(pend[2], pend[3])), min(pend[4], pend[5]));
+            K = min(K, (uint32_t)__builtin_amdgcn_mov_dpp((int)K, 0x128 /* row_ror:8 */, 0xF, 0xF, true));
+            K = min(K, (uint32_t)__builtin_amdgcn_mov_dpp((int)K, 0x124 /* row_ror:4 */, 0xF, 0xF, true));
+            K = min(K, (uint32_t)__builtin_amdgcn_mov_dpp((int)K, 0x122 /* row_ror:2 */, 0xF, 0xF, true));
+            K = min(K, (uint32_t)__builtin_amdgcn_mov_dpp((int)K, 0x121 /* row_ror:1 */, 0xF, 0xF, true));
+            {   // ... and of the other row of its pair: the left (rows 0, 1) and the right (2, 3) 16 x 8 pixels of the region
+                const auto sw = __builtin_amdgcn_permlane16_swap(K, K, false, false);
+                K = min(sw[0], sw[1]);
+            }
+            const lanemask live = __builtin_amdgcn_ballot_w64(K != NONE);   // rows that still have a face
+            if (live == 0ull) break;
+            // the vertices this lane adds to (requested now, needed after the reduction)
+            // the vertices this lane adds to (requested now, needed after the reduction)
+            const uint32_t fbase = (K != NONE ? K : 0u) * 12u;
+            const int vsel = ld_off<int32_t>(faces, fbase + 4u * (uint32_t)role_k);
             float2v accp[NR / 2];
 #pragma unroll
             for (int i = NV / 2; i < NR / 2; ++i) accp[i] = float2v{0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool m = key[j] == K;
-                pend[j] &= ~__builtin_amdgcn_ballot_w64(m);
+                const bool m = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(pend[j] == K) & live);
+                pend[j] = m ? NONE : pend[j];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float bm = m ? bk[j][k] : 0.f;
@@ -478,15 +416,16 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const bool m = lkey[e] == K;
-                const lanemask mm = __builtin_amdgcn_ballot_w64(m);
+                const lanemask mm = __builtin_amdgcn_ballot_w64(pend[4 + e] == K) & live;
                 if (mm != 0ull) {
-                    pend[4 + e] &= ~mm;
+                    const bool m = __builtin_amdgcn_inverse_ballot_w64(mm);
+                    pend[4 + e] = m ? NONE : pend[4 + e];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const float bm = m ? lb[e][k] : 0.f;
-                        accp[k * HP] = pk_fma_scalar(bm, float2v{lf[e][0], lf[e][1]}, accp[k * HP]);
-                        accp[k * HP + 1].x = fmaf(bm, lf[e][2], accp[k * HP + 1].x);
+                        accp[k * HP + IX / 2] = pk_fma_scalar(bm, float2v{lf[e][0], lf[e][1]}, accp[k * HP + IX / 2]);
+                        if (IW & 1) accp[k * HP + IW / 2].y = fmaf(bm, lf[e][2], accp[k * HP + IW / 2].y);
+                        else accp[k * HP + IW / 2].x = fmaf(bm, lf[e][2], accp[k * HP + IW / 2].x);
                     }
                 }
             }
@@ -494,11 +433,30 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             float acc[NR];
 #pragma unroll
             for (int i = 0; i < NR / 2; ++i) { acc[2 * i] = accp[i].x; acc[2 * i + 1] = accp[i].y; }
-            const float total = wave_reduce_scatter<NR>(acc, lane);
-            const int vsel0 = role_k == 0 ? a0 : (role_k == 1 ? a1 : a2), vsel1 = role_k == 0 ? b0 : (role_k == 1 ? b1 : b2);
-            const int vsel = in_group1 ? vsel1 : vsel0;
-            if (role_valid && total != 0.f)   // (a group without a face this iteration has all-zero totals)
-                atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(role_base) + (size_t)((uint32_t)vsel * role_stride)), total);
+            float d0, d1;
+            row_reduce_scatter<NR>(acc, lane, d0, d1);
+            {   // the two rows of a pair worked on the same face: their totals, added (both rows get the sum; the even one sends it)
+                const auto s0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d0), __float_as_uint(d0), false, false);
+                d0 = __uint_as_float(s0[0]) + __uint_as_float(s0[1]);
+                if (NR == 24) {
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d1), __float_as_uint(d1), false, false);
+                    d1 = __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
+                }
+            }
+            // (a pair without a face this iteration has all-zero totals)
+            const float total = odd_row ? d1 : d0;
+            // The address is formed BEFORE the branch on purpose: the wait for the vertex index then sits on every path.
+            // Inside the branch it would leave the load pending on the path around it, and the compiler answers that
+            // with s_waitcnt vmcnt(0) in the loop header -- where it also waits, every iteration, for the previous
+            // iteration's atomic to be acknowledged by the memory system (+3 us at K3, +11 us at K3-256).
+            float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(role_base) + (size_t)((uint32_t)vsel * role_stride));
+            asm volatile("" : "+v"(dst));
+#ifdef DIRT_GRAD_NO_ATOMICS
+            if (role_valid && total == 1.2345e-30f && vsel == -12345)   // (experiment: never true; keeps the operands alive)
+#else
+            if (role_valid && total != 0.f)
+#endif
+                atomicAdd(dst, total);
         }
     };
 
@@ -585,7 +543,9 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         // Per-lane predicates are kept as wave-wide lane masks in scalar registers from here on: what combines them is
         // then scalar work (s_and / s_or), and the vector unit -- what bounds this kernel -- only compares and selects.
         lanemask horiz_m[NG][4];  // [group][j]: the pixel's dilation axis is x
-        float dLx[NG][4], dLy[NG][4];
+        // dL/dx, dL/dy of :203-208 per group, as PAIRS of adjacent pixels (pair P = pixels 2P, 2P + 1 of the strip): the
+        // Scharr arithmetic below runs on such pairs with the packed fp32 instructions, two pixels per instruction
+        float2v dLx[NG][2], dLy[NG][2];
         {
             float l1x[4], l1y[4];
 #pragma unroll
@@ -593,61 +553,73 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                 const int gi = ch < G0 ? 0 : ch - G0 + 1;     // the channel's group
                 const bool single = !(ch < G0 && G0 == 3);     // a 1-channel group: quirk Q1 applies
                 const bool last_of_group = single || ch == G0 - 1;
-                // taps: t[r][0] = column x-1, t[r][1..4] = the strip, t[r][5..7] = columns x+4 .. x+6
-                float t[3][8];
+                // taps of row r as pairs: T[r][i] = columns (xs - 1 + 2i, xs + 2i); a 3-channel group needs columns
+                // xs-1 .. xs+4 (three pairs), a single xs-1 .. xs+6 (its aliased "channels" are the next two pixels)
+                constexpr int NT = 4;
+                float2v T[3][NT];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    const float* rowp = &s_pix[ch][hr - 1 + r][0];
-                    const float4 q = *reinterpret_cast<const float4*>(rowp + 4 * sx);
-                    t[r][0] = rowp[sx == 0 ? PS - 1 : 4 * sx - 1];
-                    t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
+                    const float* rowp = &s_pix[ch][hr - 1 + r][4 * sx];
+                    const float4 qa = *reinterpret_cast<const float4*>(rowp);
+                    T[r][0] = float2v{qa.x, qa.y}; T[r][1] = float2v{qa.z, qa.w};
                     if (single) {
-                        const float4 q2 = *reinterpret_cast<const float4*>(rowp + 4 * sx + 4);
-                        t[r][5] = q2.x; t[r][6] = q2.y; t[r][7] = q2.z;
+                        const float4 qb = *reinterpret_cast<const float4*>(rowp + 4);
+                        T[r][2] = float2v{qb.x, qb.y}; T[r][3] = float2v{qb.z, qb.w};
                     } else {
-                        t[r][5] = rowp[4 * sx + 4]; t[r][6] = 0.f; t[r][7] = 0.f;
+                        const float2 qb = *reinterpret_cast<const float2*>(rowp + 4);
+                        T[r][2] = float2v{qb.x, qb.y}; T[r][3] = float2v{0.f, 0.f};
                     }
                 }
-                constexpr int NQ_MAX = 6;
-                float Sx[NQ_MAX], Sy[NQ_MAX];
+                constexpr int NP_MAX = 3;
+                float2v Sx[NP_MAX], Sy[NP_MAX];
 #pragma unroll
-                for (int q = 0; q < NQ_MAX; ++q) {
-                    if (q >= 4 && !single) { Sx[q] = 0.f; Sy[q] = 0.f; continue; }
-                    // at(ox, oy): t[1 - oy][q + 1 + ox]
-                    const float mm = t[2][q], m0 = t[1][q], mp = t[0][q];
-                    const float zm = t[2][q + 1], zp = t[0][q + 1];
-                    const float pm = t[2][q + 2], p0 = t[1][q + 2], pp = t[0][q + 2];
-                    float d1 = ((mm + mp) - pm) - pp;
-                    float d2 = m0 - p0;
-                    float m1 = d1 * (3.f / 32.f), m2 = d2 * (10.f / 32.f);
-                    Sx[q] = m1 + m2;
+                for (int P = 0; P < NP_MAX; ++P) {
+                    if (P >= 2 && !single) { Sx[P] = float2v{0.f, 0.f}; Sy[P] = float2v{0.f, 0.f}; continue; }
+                    // at(ox, oy) of pixel q: row 1 - oy, column q + 1 + ox of the taps; pixels q = 2P, 2P + 1
+                    const float2v mm = T[2][P], m0 = T[1][P], mp = T[0][P];
+                    const float2v pm = T[2][P + 1], p0 = T[1][P + 1], pp = T[0][P + 1];
+                    float2v d1 = ((mm + mp) - pm) - pp;
+                    float2v d2 = m0 - p0;
+                    float2v m1 = d1 * (3.f / 32.f), m2 = d2 * (10.f / 32.f);
+                    Sx[P] = m1 + m2;
                     d1 = ((mm + pm) - mp) - pp;
-                    d2 = zm - zp;
+                    // the middle column of each pixel: the high half of one tap pair and the low half of the next
+                    d2.x = T[2][P].y - T[0][P].y;
+                    d2.y = T[2][P + 1].x - T[0][P + 1].x;
                     m1 = d1 * (3.f / 32.f); m2 = d2 * (10.f / 32.f);
-                    Sy[q] = m1 + m2;
+                    Sy[P] = m1 + m2;
                 }
+                auto comp = [](const float2v (&v)[NP_MAX], int q) { return (q & 1) ? v[q >> 1].y : v[q >> 1].x; };
                 if (!single) {
 #pragma unroll
+                    for (int P = 0; P < 2; ++P) {
+                        const float2v gp = float2v{g[2 * P][ch], g[2 * P + 1][ch]};
+                        float2v m = gp * Sx[P];
+                        dLx[gi][P] = ch == 0 ? m : dLx[gi][P] + m;
+                        m = gp * Sy[P];
+                        dLy[gi][P] = ch == 0 ? m : dLy[gi][P] + m;
+                    }
+#pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float m = g[j][ch] * Sx[j];
-                        dLx[gi][j] = ch == 0 ? m : dLx[gi][j] + m;
-                        m = g[j][ch] * Sy[j];
-                        dLy[gi][j] = ch == 0 ? m : dLy[gi][j] + m;
-                        l1x[j] = ch == 0 ? fabsf(Sx[j]) : l1x[j] + fabsf(Sx[j]);
-                        l1y[j] = ch == 0 ? fabsf(Sy[j]) : l1y[j] + fabsf(Sy[j]);
+                        l1x[j] = ch == 0 ? fabsf(comp(Sx, j)) : l1x[j] + fabsf(comp(Sx, j));
+                        l1y[j] = ch == 0 ? fabsf(comp(Sy, j)) : l1y[j] + fabsf(comp(Sy, j));
                     }
                 } else {
 #pragma unroll
+                    for (int P = 0; P < 2; ++P) {
+                        const float2v gp = float2v{g[2 * P][ch], g[2 * P + 1][ch]};
+                        dLx[gi][P] = gp * Sx[P];
+                        dLy[gi][P] = gp * Sy[P];
+                    }
+#pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        dLx[gi][j] = g[j][ch] * Sx[j];
-                        dLy[gi][j] = g[j][ch] * Sy[j];
                         // quirk Q1: "channels" 1,2 of a 1-channel group = elements (pixel + 1, + 2) of the flattened
                         // [B,H,W,1] slice.  Only the L1 norms of interior pixels use them, and for an interior pixel the
                         // taps are unclamped: column + ch, which is staged unless it runs past the end of the image row
                         // (the last two interior columns of the frame are corrected below: alias_wrap_fixup)
-                        const float a0x = fabsf(Sx[j]), a0y = fabsf(Sy[j]);
-                        l1x[j] = q1_intended ? a0x : (a0x + fabsf(Sx[j + 1])) + fabsf(Sx[j + 2]);
-                        l1y[j] = q1_intended ? a0y : (a0y + fabsf(Sy[j + 1])) + fabsf(Sy[j + 2]);
+                        const float a0x = fabsf(comp(Sx, j)), a0y = fabsf(comp(Sy, j));
+                        l1x[j] = q1_intended ? a0x : (a0x + fabsf(comp(Sx, j + 1))) + fabsf(comp(Sx, j + 2));
+                        l1y[j] = q1_intended ? a0y : (a0y + fabsf(comp(Sy, j + 1))) + fabsf(comp(Sy, j + 2));
                     }
                 }
                 if (last_of_group) {
@@ -762,7 +734,8 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                     if (cbase == 0 && gi == 0 && in_px[j]) write_debug(p.debug_thingy, p.grad_pixels, p.B, H, W, C, iib, y, xs + j, G0, dilated);
                 }
                 const float rcp_w = __builtin_amdgcn_rcpf(clip_w);
-                float2v f = (float2v{dLx[gi][j], dLy[gi][j]} * half_size) * float2v{rcp_w, rcp_w};
+                const float dLx_j = (j & 1) ? dLx[gi][j >> 1].y : dLx[gi][j >> 1].x, dLy_j = (j & 1) ? dLy[gi][j >> 1].y : dLy[gi][j >> 1].x;
+                float2v f = (float2v{dLx_j, dLy_j} * half_size) * float2v{rcp_w, rcp_w};
                 const bool own = __builtin_amdgcn_inverse_ballot_w64(m_cov & ~dil);   // contributes to its own pixel
                 fxy[j][0] += own ? f.x : 0.f;
                 fxy[j][1] += own ? f.y : 0.f;

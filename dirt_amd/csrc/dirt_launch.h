@@ -71,8 +71,9 @@ struct GradParams {
     const float* pixels;       // [B,H,W,C]
     const float* grad_pixels;  // [B,H,W,C]
     float* grad_background;    // [B,H,W,C]
-    float* grad_vertices;      // [B,V,4]  (zeroed before launch)
-    float* grad_vertex_colors; // [B,V,C]  (zeroed before launch)
+    float* grad_vertices;      // [B,V,4]  (zeroed before launch), rows of gv_stride floats
+    float* grad_vertex_colors; // [B,V,C]  (zeroed before launch), rows of gvc_stride floats
+    int gv_stride, gvc_stride; // 4 and C for dense tensors; 8 and 8 for the state's interleaved accumulators
     float* debug_thingy;       // [B,H,W,3] or nullptr
     int B, V, F, H, W, C;
     unsigned flags;

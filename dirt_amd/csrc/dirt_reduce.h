@@ -1,0 +1,87 @@
+// dirt_reduce.h -- the cross-lane reduction of the gradient kernel's face loop (gfx950 DPP), kept apart so that
+// tools/reduce_test.hip can check the lane mapping on the device.
+//
+// A wave is four DPP ROWS of 16 lanes; in dirt_grad.hip a row holds one 8 x 8 pixel block.  row_reduce_scatter<N> sums
+// N (16 or 24) per-lane values over the 16 lanes of every row at once, with a transposing butterfly: at each of the
+// four levels a lane is paired with the lane that differs in one lane bit and value i with value i + (half of what is
+// left); the lane keeps one of the two values, sends the other to its partner and adds what it receives, so registers
+// halve while lanes specialise.  Lane bits 3 and 2 select DPP BANKS (groups of four lanes), so those levels are two
+// bank-masked v_add_f32_dpp per pair and no selects (inline assembly: the masked form has no builtin); bits 1 and 0 are
+// quad permutations (two selects and one DPP add per pair).  N = 24: 24 + 12 + 9 + 4 = 49 instructions for the totals
+// of 24 values x 4 rows; a plain DPP row sum of every value would be 96 + the selects.
+//
+// Where the totals end up (row_value_of_lane): with b_k = bit k of the lane,
+//     N = 16:  d0 = total of value  b0 + 2 b1 + 4 b2 + 8 b3                         (one value per lane)
+//     N = 24:  d0 = total of value  b0 + 3 b1 + 6 b2 + 12 b3,
+//              d1 = total of value  2 + 3 b1 + 6 b2 + 12 b3   (in both lanes of a b0 pair: the even lane uses it)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dirt {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// keep `lo` (lower lane of the pair) or `hi` (upper lane), add what the partner sends
+template <int CTRL>
+__device__ __forceinline__ float pack_pair(float lo, float hi, bool upper)
+{
+    const float keep = upper ? hi : lo, send = upper ? lo : hi;
+    return keep + dpp_mov<CTRL>(send);
+}
+
+// The levels whose "upper" lanes are whole DPP banks.  A DPP operand written by the preceding VALU instruction needs
+// two wait states: the leading s_nop.
+// bit 3 (lanes 8-15 of a row = banks 2, 3): lo + partner's lo everywhere, then hi + partner's hi in the upper banks.
+__device__ __forceinline__ float pack_pair_bit3(float lo, float hi)
+{
+    float r;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// bit 2 (banks 1, 3 are the upper lanes): banks 0, 2 take lo + lo of the lane four above (row_shl:4), banks 1, 3 take
+// hi + hi of the lane four below (row_shr:4).
+__device__ __forceinline__ float pack_pair_bit2(float lo, float hi)
+{
+    float r;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
+        : "=&v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <int N>
+__device__ __forceinline__ void row_reduce_scatter(const float* val, int lane, float& d0, float& d1)
+{
+    static_assert(N == 16 || N == 24, "16 or 24 values");
+    constexpr int QUAD_XOR2 = 0x4E /* [2,3,0,1] */, QUAD_XOR1 = 0xB1 /* [1,0,3,2] */;
+    const bool u1 = (lane & 2) != 0, u0 = (lane & 1) != 0;
+    float a[N / 2], b[N / 4], c[N / 8];
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) a[i] = pack_pair_bit3(val[i], val[i + N / 2]);
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) b[i] = pack_pair_bit2(a[i], a[i + N / 4]);
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i) c[i] = pack_pair<QUAD_XOR2>(b[i], b[i + N / 8], u1);
+    d0 = pack_pair<QUAD_XOR1>(c[0], c[1], u0);
+    d1 = 0.f;
+    if (N == 24) d1 = c[2] + dpp_mov<QUAD_XOR1>(c[2]);
+}
+
+// The values whose row totals row_reduce_scatter<N> leaves in `lane`: v0 (d0) and v1 (d1; -1: none).
+template <int N>
+__device__ __forceinline__ void row_value_of_lane(int lane, int& v0, int& v1)
+{
+    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1;
+    if (N == 16) { v0 = b0 + 2 * b1 + 4 * b2 + 8 * b3; v1 = -1; }
+    else { v0 = b0 + 3 * b1 + 6 * b2 + 12 * b3; v1 = b0 ? -1 : 2 + 3 * b1 + 6 * b2 + 12 * b3; }
+}
+
+}  // namespace dirt

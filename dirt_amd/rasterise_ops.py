@@ -141,6 +141,8 @@ def _op_rasterise(background, vertices, vertex_colors, faces, height, width, cha
         _lib.check(lib.dirt_rasterise_forward(
             background.data_ptr(), vertices.data_ptr(), vertex_colors.data_ptr(), faces.data_ptr(), pixels.data_ptr(),
             B, V, F, height, width, channels, ws.data_ptr(), ws.numel(), flags, torch.cuda.current_stream(dev).cuda_stream))
+    if keep_state:
+        ws._dirt_channels = channels   # the layout of the state's gradient accumulators depends on the channel count
     return (pixels, ws) if keep_state else pixels
 
 
@@ -171,6 +173,8 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
             raise ValueError(_lib.last_error())
         if state is not None and state.numel() < nbytes:
             state = None  # sized for fewer channels than this call has: render again
+        if state is not None and getattr(state, '_dirt_channels', channels) != channels:
+            state_outputs = False  # the accumulators inside the state were laid out (and cleared) for another channel count
         if state is not None and not state_outputs:
             ws = state
             flags |= _lib.FLAG_REUSE_STATE
@@ -181,12 +185,16 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
             # the returned tensors are views of it
             ws = state
             flags |= _lib.FLAG_REUSE_STATE
-            gv_p, gvc_p = ctypes.c_void_p(), ctypes.c_void_p()
+            gv_p, gvc_p, gv_s, gvc_s = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
             _lib.check(lib.dirt_state_grad_buffers(ws.data_ptr(), ws.numel(), B, V, F, height, width, channels,
-                                                   ctypes.byref(gv_p), ctypes.byref(gvc_p)))
-            o1, o2 = gv_p.value - ws.data_ptr(), gvc_p.value - ws.data_ptr()
-            grad_vertices = ws[o1:o1 + B * V * 16].view(torch.float32).view(B, V, 4)
-            grad_vertex_colors = ws[o2:o2 + B * V * channels * 4].view(torch.float32).view(B, V, channels)
+                                                   ctypes.byref(gv_p), ctypes.byref(gvc_p), ctypes.byref(gv_s), ctypes.byref(gvc_s)))
+            # rows of gv_s / gvc_s floats (C <= 4: both accumulators interleaved in rows of 8): strided views
+            wsf = ws.view(torch.float32) if ws.data_ptr() % 4 == 0 and ws.numel() % 4 == 0 else None
+            if wsf is None:
+                raise RuntimeError('state workspace is not float-aligned')
+            o1, o2 = (gv_p.value - ws.data_ptr()) // 4, (gvc_p.value - ws.data_ptr()) // 4
+            grad_vertices = torch.as_strided(wsf, (B, V, 4), (V * gv_s.value, gv_s.value, 1), o1)
+            grad_vertex_colors = torch.as_strided(wsf, (B, V, channels), (V * gvc_s.value, gvc_s.value, 1), o2)
         else:
             ws = _workspace(dev, nbytes)
             grad_vertices = torch.empty_like(vertices)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DIRT_ABI_VERSION 1
+#define DIRT_ABI_VERSION 2
 
 /* error codes */
 #define DIRT_OK 0
@@ -128,14 +128,19 @@ int dirt_rasterise_visibility(const float *vertices, const int32_t *faces, int32
                               void *stream);
 
 /*
- * With DIRT_FLAG_KEEP_STATE the forward pass also clears two gradient accumulators inside the workspace
- * ([B,V,4] and [B,V,C] floats).  This returns their addresses: a backward call with DIRT_FLAG_REUSE_STATE
- * whose grad_vertices / grad_vertex_colors ARE these pointers accumulates straight into them and needs no
- * clearing launch (the reference clears its outputs with four cudaMemsetAsync,
- * csrc/rasterise_grad_egl.cu:244-250).  Any other output pointers work too; they are cleared first.
+ * With DIRT_FLAG_KEEP_STATE the forward pass also clears the gradient accumulators inside the workspace.  This
+ * returns their addresses and ROW STRIDES (in floats): a backward call with DIRT_FLAG_REUSE_STATE whose grad_vertices /
+ * grad_vertex_colors ARE these pointers accumulates straight into them and needs no clearing launch (the reference
+ * clears its outputs with four cudaMemsetAsync, csrc/rasterise_grad_egl.cu:244-250).  Any other output pointers work
+ * too; they are dense ([B,V,4] and [B,V,C]) and are cleared first.
+ *   For C <= 4 the two accumulators are INTERLEAVED: one row of 8 floats per vertex, {x, y, z, w, c0 .. c3}, so both
+ * strides are 8 and *grad_vertex_colors == *grad_vertices + 4: a face adds its seven values per vertex to one 32-byte
+ * row, which is what the memory system's float atomics are priced by (tools/atomic_bench.hip).  For C > 4 they are
+ * dense: strides 4 and C.  View them as strided tensors ([B,V,4] with strides (8V, 8, 1) ...).
  */
 int dirt_state_grad_buffers(void *workspace, size_t workspace_bytes, int B, int V, int F, int H, int W, int C,
-                            float **grad_vertices, float **grad_vertex_colors);
+                            float **grad_vertices, float **grad_vertex_colors, int *grad_vertices_row_stride,
+                            int *grad_vertex_colors_row_stride);
 
 /*
  * Texture look-up of a deferred shader, fused.  Replaces the TensorFlow composition
