@@ -129,16 +129,18 @@ __global__ __launch_bounds__(STHREADS) void setup_kernel(GeomParams g)
         if (lane >= d) incl += t;
     }
     uint32_t start = incl - sum;
-    BinCell* __restrict__ row = g.cells + ((size_t)ib * g.nchunk + chunk) * (MAX_BINS + 1);
+    // the directory is stored bin-major, [bin][chunk]: what a raster tile reads -- its bin's cell of every chunk -- is
+    // then contiguous (nchunk x 8 bytes = a few lines, instead of one line per chunk)
+    BinCell* __restrict__ col = g.cells + (size_t)ib * (MAX_BINS + 1) * g.nchunk + chunk;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         s_start[4 * lane + i] = start;
-        row[4 * lane + i] = BinCell{start, cnt[i]};
+        col[(size_t)(4 * lane + i) * g.nchunk] = BinCell{start, cnt[i]};
         start += cnt[i];
     }
     if (lane == STHREADS - 1) {
         s_start[MAX_BINS] = start;
-        row[MAX_BINS] = BinCell{start, s_cnt[MAX_BINS]};
+        col[(size_t)MAX_BINS * g.nchunk] = BinCell{start, s_cnt[MAX_BINS]};
     }
     __syncthreads();
 #pragma unroll
@@ -170,7 +172,8 @@ __global__ __launch_bounds__(STHREADS) void setup_kernel(GeomParams g)
 // NB = 2 (32 x 32 tiles, one record fetch serves 256 pixels) is the normal shape; NB = 1 (16 x 16 tiles) gives four
 // times as many workgroups for small frames, where 32 x 32 tiles would leave most of the 1024 SIMDs idle.
 constexpr int RTHREADS = 256;     // 4 waves: one per region
-constexpr int LIST_CAP = 1024;    // candidates listed per round
+constexpr int LIST_CAP = 1024;    // candidates listed per round: four segments, one per wave
+constexpr int SEG_CAP = LIST_CAP / 4;
 constexpr int SHADE_CAP = 96;     // candidates whose set-up record (and vertex colours) stay in LDS for the shading pass
 
 // What the coverage / depth loop reads per candidate: built once per (tile, candidate) by one lane when the
@@ -304,7 +307,7 @@ __device__ __forceinline__ void store_state(const RasterParams& p, size_t pix, f
 //            records in LDS, exports the state, interpolates the colours (requested per candidate at staging, left in
 //            LDS after the candidate loop) and writes the HWC pixels (background copied where uncovered).
 template <int MODE, int NB, int CSPEC>
-__global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
+__global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
 {
     constexpr int TILE = 16 * NB;                      // pixels
     constexpr int BT = 2 * NB;                         // blocks per tile side: block (bx, by) = mask bit BT * by + bx
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
     constexpr bool LDS_COLORS = MODE == 0 && CSPEC != 0;
     __shared__ int32_t s_face[LIST_CAP];
     __shared__ uint16_t s_mask[LIST_CAP];  // bit (BT*by + bx): the face's box touches block (bx, by) of the tile
-    __shared__ uint32_t s_count;
+    __shared__ uint32_t s_cnt[4];          // entries in each wave's segment of the list
     __shared__ TileRec s_rec[64];          // tile-local records of the 64 list entries being rasterised
     __shared__ FaceRec s_shade[SHADE_CAP]; // the set-up records of the first listed candidates, for the shading pass
     __shared__ float4 s_col[LDS_COLORS ? SHADE_CAP : 1][3];  // ... and their vertex colours (channel-specialised kernels)
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
 
     const FaceRec* __restrict__ recs = p.recs + (size_t)ib * p.F;
     const int bin = (tr0 >> p.grid.shift) * p.grid.bins_x + (tx0 >> p.grid.shift);
-    // column `bin` (and the big pseudo-bin) of the chunk x bin directory: the 2 * nchunk runs (chunk, bin) then (chunk, big)
+    // rows `bin` and "big" of the bin x chunk directory: the 2 * nchunk runs (chunk, bin) then (chunk, big)
     const BinCell* __restrict__ cells = p.cells + (size_t)ib * p.nchunk * (MAX_BINS + 1);
     const BinEntry* __restrict__ scene_entries = p.entries + (size_t)ib * p.nchunk * (5 * (size_t)p.chunk_faces);
     const int nruns = 2 * p.nchunk;  // <= 512: two per thread
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
         run_base[k] = 0; run_count[k] = 0; run_pos[k] = 0;
         if (j < nruns) {
             const int c = j < p.nchunk ? j : j - p.nchunk;
-            const BinCell cell = cells[(size_t)c * (MAX_BINS + 1) + (j < p.nchunk ? bin : MAX_BINS)];
+            const BinCell cell = cells[(size_t)(j < p.nchunk ? bin : MAX_BINS) * p.nchunk + c];
             run_base[k] = (uint32_t)c * (5u * (uint32_t)p.chunk_faces) + cell.start;
             run_count[k] = cell.count;
         }
@@ -384,8 +387,8 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
 
     TRACE_MARK();  // 1: directory requested
     for (int round = 0;; ++round) {
-        if (tid == 0) s_count = 0;
-        __syncthreads();
+        // every wave appends to its own segment of the list: its counter needs no barrier (the LDS serves a wave in order)
+        if (lane == 0) s_cnt[wave] = 0;
         TRACE_MARK();  // 2: cleared, barrier
         // ---- scan: this thread's runs, four entries per trip ----
         bool full = false;
@@ -404,15 +407,15 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
                     if (run_pos[k] >= run_count[k] || full) break;
                     const FaceBox box = en[i].box;
                     if (box.i_min <= tx1 && box.i_max >= tx0 && box.r_min <= tr1 && box.r_max >= tr0) {
-                        const uint32_t slot = atomicAdd(&s_count, 1u);
-                        if (slot >= (uint32_t)LIST_CAP) { full = true; break; }   // not consumed: next round
+                        const uint32_t slot = atomicAdd(&s_cnt[wave], 1u);
+                        if (slot >= (uint32_t)SEG_CAP) { full = true; break; }   // not consumed: next round
                         const int bx0 = max(box.i_min - tx0, 0) >> 3, bx1 = min(box.i_max - tx0, TILE - 1) >> 3;
                         const int by0 = max(box.r_min - tr0, 0) >> 3, by1 = min(box.r_max - tr0, TILE - 1) >> 3;
                         const uint32_t rowbits = ((2u << bx1) - (1u << bx0)) & ((1u << BT) - 1u);
                         uint32_t mask = 0;
                         for (int by = by0; by <= by1; ++by) mask |= rowbits << (BT * by);
-                        s_face[slot] = en[i].face;
-                        s_mask[slot] = (uint16_t)mask;
+                        s_face[wave * SEG_CAP + slot] = en[i].face;
+                        s_mask[wave * SEG_CAP + slot] = (uint16_t)mask;
                         // the staging pass reads this face's set-up record (one 128-byte line, written by another XCD's
                         // set-up workgroup) after the list barrier: touch it now, so that it is on its way to this
                         // XCD's L2 while the list is still being built.  The loaded word is never used; `touch` stays
@@ -426,7 +429,13 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
         TRACE_MARK();  // 3: appended
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch));
         __syncthreads();
-        const int n = (int)min(s_count, (uint32_t)LIST_CAP);
+        // the list: the four segments one after the other
+        const int n0 = (int)min(s_cnt[0], (uint32_t)SEG_CAP), n1 = (int)min(s_cnt[1], (uint32_t)SEG_CAP);
+        const int n2 = (int)min(s_cnt[2], (uint32_t)SEG_CAP), n3 = (int)min(s_cnt[3], (uint32_t)SEG_CAP);
+        const int p1 = n0, p2 = n0 + n1, p3 = n0 + n1 + n2, n = p3 + n3;
+        auto slot_of = [&](int i) {   // list index -> position in s_face / s_mask
+            return i < p1 ? i : (i < p2 ? SEG_CAP + i - p1 : (i < p3 ? 2 * SEG_CAP + i - p2 : 3 * SEG_CAP + i - p3));
+        };
         if (round != 0) lds_records = false;
         TRACE_MARK();  // 4: list built
 
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
             float4 colv0 = make_float4(0.f, 0.f, 0.f, 0.f), colv1 = colv0, colv2 = colv0;
             bool stage_colors = false;
             if (tid < m_chunk) {
-                const int face = s_face[cb + tid];
+                const int face = s_face[slot_of(cb + tid)];
                 const FaceRec rec = recs[face];
                 make_tile_rec(rec, face, (double)tx0 + 0.5, (double)(p.H - 1 - tr0) + 0.5, wf, hf, &s_rec[tid]);
                 if (round == 0 && cb + tid < SHADE_CAP) {
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
             const int idx = cb + lane;
             uint32_t mym4 = 0;
             if (idx < n) {
-                const uint32_t mk = s_mask[idx];
+                const uint32_t mk = s_mask[slot_of(idx)];
                 // the wave's block bits inside the tile mask, gathered into NB * NB bits (NB * by + bx)
 #pragma unroll
                 for (int by = 0; by < NB; ++by)
@@ -514,91 +523,90 @@ __global__ __launch_bounds__(RTHREADS) void raster_kernel(RasterParams p)
             else bgv[k] = make_float4(bg[0], 0.f, 0.f, 0.f);
         }
     }
-    // barycentrics of the winners (csrc/shaders.cpp:52-57,74), from the records in LDS or, for candidates beyond
-    // SHADE_CAP / later rounds, in memory; the backward pass's state and the visibility export
-    float bary[PPL][3];
-    int32_t vids[PPL][3];
+    // Per pixel: barycentrics of the winner (csrc/shaders.cpp:52-57,74) from its record in LDS -- or, for candidates beyond
+    // SHADE_CAP / later rounds, in memory --, the backward pass's state, the interpolated colours, the HWC pixel.  The LDS
+    // reads are written as such (indexing s_shade / s_col, not through a pointer that may also point to memory: that
+    // would be flat loads, each waiting for LDS AND memory, i.e. for the stores of the pixel before); the rare records in
+    // memory are fetched behind a wave-uniform branch.
+    const float* __restrict__ cols = p.vertex_colors + (size_t)ib * p.V * C;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
         const int32_t f = fbest[k];
-        bary[k][0] = bary[k][1] = bary[k][2] = 0.f;
-        vids[k][0] = vids[k][1] = vids[k][2] = 0;
-        float cw = INFINITY, b0 = -1.f, b1 = -1.f;
-        if (f >= 0) {
-            const bool in_lds = lds_records && cbest[k] < SHADE_CAP;
-            const FaceRec* rec = in_lds ? &s_shade[cbest[k]] : recs + f;   // (a generic pointer: LDS or memory)
-            double cf[9];
+        const bool has = f >= 0;
+        const bool from_lds = has && lds_records && cbest[k] < SHADE_CAP;
+        const int ci = from_lds ? cbest[k] : 0;   // (lanes without a winner read slot 0; what they compute is not used)
+        double cf[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) cf[i] = rec->coef[i];
-            double Fk[3];
-            edge_eval(cf, (double)(x0 + 8 * (k % NB)) + 0.5, (double)(p.H - 1 - (r0 + 8 * (k / NB))) + 0.5, Fk);
-            float b[3];
-            bary_eval(Fk, rec->flags, rec->inv_det, b, cw);
-            bary[k][0] = b[0]; bary[k][1] = b[1]; bary[k][2] = b[2];
-            b0 = b[0]; b1 = b[1];
-            if (MODE == 0 && !(LDS_COLORS && in_lds)) { vids[k][0] = rec->vid[0]; vids[k][1] = rec->vid[1]; vids[k][2] = rec->vid[2]; }
-        }
-        if (inside[k]) {
-            if (p.vis) p.vis[pix[k]] = f;
-            if (p.state_a) store_state(p, pix[k], b0, b1, cw, f);
-        }
-    }
-    if (MODE == 0) {
-        const float* __restrict__ cols = p.vertex_colors + (size_t)ib * p.V * C;
+        for (int i = 0; i < 9; ++i) cf[i] = s_shade[ci].coef[i];
+        uint32_t flags = s_shade[ci].flags;
+        double inv_det = s_shade[ci].inv_det;
+        int32_t vid0 = 0, vid1 = 0, vid2 = 0;
+        if (MODE == 0 && !LDS_COLORS) { vid0 = s_shade[ci].vid[0]; vid1 = s_shade[ci].vid[1]; vid2 = s_shade[ci].vid[2]; }
+        float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0, u2 = u0;
+        if (LDS_COLORS) { u0 = s_col[ci][0]; u1 = s_col[ci][1]; u2 = s_col[ci][2]; }
+        if (__builtin_amdgcn_ballot_w64(has && !from_lds) != 0ull) {
+            if (has && !from_lds) {
+                const FaceRec* __restrict__ rec = recs + f;
 #pragma unroll
-        for (int k = 0; k < PPL; ++k) {
-            if (!inside[k]) continue;
-            const int32_t f = fbest[k];
-            float* __restrict__ out = p.pixels + pix[k] * C;
-            if (CSPEC != 0) {
-                float4 o = bgv[k];   // pixels start as the background: csrc/rasterise_egl.cpp:348-356
-                if (f >= 0) {
-                    float4 u0, u1, u2;
-                    if (lds_records && cbest[k] < SHADE_CAP) {
-                        u0 = s_col[cbest[k]][0]; u1 = s_col[cbest[k]][1]; u2 = s_col[cbest[k]][2];
-                    } else {
-                        const float* __restrict__ c0 = cols + (size_t)vids[k][0] * C;
-                        const float* __restrict__ c1 = cols + (size_t)vids[k][1] * C;
-                        const float* __restrict__ c2 = cols + (size_t)vids[k][2] * C;
-                        if (CSPEC == 4) { u0 = *reinterpret_cast<const float4*>(c0); u1 = *reinterpret_cast<const float4*>(c1); u2 = *reinterpret_cast<const float4*>(c2); }
-                        else if (CSPEC == 3) { u0 = make_float4(c0[0], c0[1], c0[2], 0.f); u1 = make_float4(c1[0], c1[1], c1[2], 0.f); u2 = make_float4(c2[0], c2[1], c2[2], 0.f); }
-                        else { u0 = make_float4(c0[0], 0.f, 0.f, 0.f); u1 = make_float4(c1[0], 0.f, 0.f, 0.f); u2 = make_float4(c2[0], 0.f, 0.f, 0.f); }
-                    }
-                    const float b0 = bary[k][0], b1 = bary[k][1], b2 = bary[k][2];
-                    o.x = fmaf(b2, u2.x, fmaf(b1, u1.x, b0 * u0.x));
-                    if (CSPEC >= 3) { o.y = fmaf(b2, u2.y, fmaf(b1, u1.y, b0 * u0.y)); o.z = fmaf(b2, u2.z, fmaf(b1, u1.z, b0 * u0.z)); }
-                    if (CSPEC == 4) o.w = fmaf(b2, u2.w, fmaf(b1, u1.w, b0 * u0.w));
+                for (int i = 0; i < 9; ++i) cf[i] = rec->coef[i];
+                flags = rec->flags; inv_det = rec->inv_det;
+                vid0 = rec->vid[0]; vid1 = rec->vid[1]; vid2 = rec->vid[2];
+                if (LDS_COLORS) {
+                    const float* __restrict__ c0 = cols + (size_t)vid0 * C;
+                    const float* __restrict__ c1 = cols + (size_t)vid1 * C;
+                    const float* __restrict__ c2 = cols + (size_t)vid2 * C;
+                    if (CSPEC == 4) { u0 = *reinterpret_cast<const float4*>(c0); u1 = *reinterpret_cast<const float4*>(c1); u2 = *reinterpret_cast<const float4*>(c2); }
+                    else if (CSPEC == 3) { u0 = make_float4(c0[0], c0[1], c0[2], 0.f); u1 = make_float4(c1[0], c1[1], c1[2], 0.f); u2 = make_float4(c2[0], c2[1], c2[2], 0.f); }
+                    else { u0 = make_float4(c0[0], 0.f, 0.f, 0.f); u1 = make_float4(c1[0], 0.f, 0.f, 0.f); u2 = make_float4(c2[0], 0.f, 0.f, 0.f); }
                 }
-                if (CSPEC == 4) *reinterpret_cast<float4*>(out) = o;
-                else if (CSPEC == 3) { out[0] = o.x; out[1] = o.y; out[2] = o.z; }
-                else out[0] = o.x;
-            } else if (f < 0) {
-                const float* __restrict__ bg = p.background + pix[k] * C;
-                if ((C & 3) == 0) {
-                    for (int c = 0; c < C; c += 4) *reinterpret_cast<float4*>(out + c) = *reinterpret_cast<const float4*>(bg + c);
-                } else {
-                    for (int c = 0; c < C; ++c) out[c] = bg[c];
+            }
+        }
+        double Fk[3];
+        edge_eval(cf, (double)(x0 + 8 * (k % NB)) + 0.5, (double)(p.H - 1 - (r0 + 8 * (k / NB))) + 0.5, Fk);
+        float b[3], cw;
+        bary_eval(Fk, flags, inv_det, b, cw);
+        const float b0 = b[0], b1 = b[1], b2 = b[2];
+        if (!inside[k]) continue;
+        // the backward pass's state and the visibility export
+        if (p.vis) p.vis[pix[k]] = f;
+        if (p.state_a) store_state(p, pix[k], has ? b0 : -1.f, has ? b1 : -1.f, has ? cw : INFINITY, f);
+        if (MODE != 0) continue;
+        float* __restrict__ out = p.pixels + pix[k] * C;
+        if (CSPEC != 0) {
+            float4 o = bgv[k];   // pixels start as the background: csrc/rasterise_egl.cpp:348-356
+            if (has) {
+                o.x = fmaf(b2, u2.x, fmaf(b1, u1.x, b0 * u0.x));
+                if (CSPEC >= 3) { o.y = fmaf(b2, u2.y, fmaf(b1, u1.y, b0 * u0.y)); o.z = fmaf(b2, u2.z, fmaf(b1, u1.z, b0 * u0.z)); }
+                if (CSPEC == 4) o.w = fmaf(b2, u2.w, fmaf(b1, u1.w, b0 * u0.w));
+            }
+            if (CSPEC == 4) *reinterpret_cast<float4*>(out) = o;
+            else if (CSPEC == 3) { out[0] = o.x; out[1] = o.y; out[2] = o.z; }
+            else out[0] = o.x;
+        } else if (!has) {
+            const float* __restrict__ bg = p.background + pix[k] * C;
+            if ((C & 3) == 0) {
+                for (int c = 0; c < C; c += 4) *reinterpret_cast<float4*>(out + c) = *reinterpret_cast<const float4*>(bg + c);
+            } else {
+                for (int c = 0; c < C; ++c) out[c] = bg[c];
+            }
+        } else {
+            const float* __restrict__ c0 = cols + (size_t)vid0 * C;
+            const float* __restrict__ c1 = cols + (size_t)vid1 * C;
+            const float* __restrict__ c2 = cols + (size_t)vid2 * C;
+            if ((C & 3) == 0) {
+                for (int c = 0; c < C; c += 4) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(c0 + c);
+                    const float4 w1 = *reinterpret_cast<const float4*>(c1 + c);
+                    const float4 w2 = *reinterpret_cast<const float4*>(c2 + c);
+                    float4 o;
+                    o.x = fmaf(b2, w2.x, fmaf(b1, w1.x, b0 * w0.x));
+                    o.y = fmaf(b2, w2.y, fmaf(b1, w1.y, b0 * w0.y));
+                    o.z = fmaf(b2, w2.z, fmaf(b1, w1.z, b0 * w0.z));
+                    o.w = fmaf(b2, w2.w, fmaf(b1, w1.w, b0 * w0.w));
+                    *reinterpret_cast<float4*>(out + c) = o;
                 }
             } else {
-                const float* __restrict__ c0 = cols + (size_t)vids[k][0] * C;
-                const float* __restrict__ c1 = cols + (size_t)vids[k][1] * C;
-                const float* __restrict__ c2 = cols + (size_t)vids[k][2] * C;
-                const float b0 = bary[k][0], b1 = bary[k][1], b2 = bary[k][2];
-                if ((C & 3) == 0) {
-                    for (int c = 0; c < C; c += 4) {
-                        const float4 u0 = *reinterpret_cast<const float4*>(c0 + c);
-                        const float4 u1 = *reinterpret_cast<const float4*>(c1 + c);
-                        const float4 u2 = *reinterpret_cast<const float4*>(c2 + c);
-                        float4 o;
-                        o.x = fmaf(b2, u2.x, fmaf(b1, u1.x, b0 * u0.x));
-                        o.y = fmaf(b2, u2.y, fmaf(b1, u1.y, b0 * u0.y));
-                        o.z = fmaf(b2, u2.z, fmaf(b1, u1.z, b0 * u0.z));
-                        o.w = fmaf(b2, u2.w, fmaf(b1, u1.w, b0 * u0.w));
-                        *reinterpret_cast<float4*>(out + c) = o;
-                    }
-                } else {
-                    for (int c = 0; c < C; ++c) out[c] = fmaf(b2, c2[c], fmaf(b1, c1[c], b0 * c0[c]));
-                }
+                for (int c = 0; c < C; ++c) out[c] = fmaf(b2, c2[c], fmaf(b1, c1[c], b0 * c0[c]));
             }
         }
     }
