@@ -19,6 +19,8 @@ FLAG_PROFILE = 0x100
 FLAG_TILES_LARGE = 0x200
 FLAG_TILES_SMALL = 0x400
 FLAG_SHARED_FACES = 0x800
+FLAG_GRAD_ROWS = 0x1000    # gradient kernel: every 8x8 block walks its own faces (default for small frames)
+FLAG_GRAD_PAIRS = 0x2000   # ... or pairs of blocks share a face (default otherwise)
 TEX_CLAMP = 1
 TEX_NEAREST = 2
 

@@ -177,7 +177,10 @@ __device__ __forceinline__ void st_off(void* base, uint32_t off, T v)
 // what one pass brings in from HBM the others find there.  grad_vertices is summed over the groups by the atomics
 // (dirt/rasterise_ops.py:167-171).
 // DEBUG: also write the reference's diagnostic output debug_thingy.
-template <int CSPEC, bool STRIDED, bool DEBUG>
+// ROWS: every DPP row (8 x 8 pixels) of a wave walks its own faces -- four faces per face-loop iteration, ~5 iterations
+// where the pairs of rows need ~6.4, but ~1.6 x the float atomics: launched where the memory system has room for them
+// (small frames); otherwise the two rows of a pair (16 x 8 pixels) work on one face.
+template <int CSPEC, bool STRIDED, bool DEBUG, bool ROWS = false>
 __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 {
     static_assert(CSPEC == 1 || CSPEC == 3 || CSPEC == 4, "pass shapes");
@@ -353,18 +356,27 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         static_assert((IX & 1) == 0 && IY < S && IW < S, "");
         // this lane's roles: it adds the row totals of values rv[0], rv[1] of the row's face (row_value_of_lane): vertex
         // rv / S, component c = rv % S: c < NCHV: colour c; IX, IY, IW: (x, y, w) of grad_vertices
-        // (the two rows of a pair end up with the same totals -- see the end of an iteration -- so the even row sends d0's
-        // value and the odd row d1's: one atomic instruction per iteration)
-        int rv0, rv1;
-        row_value_of_lane<NR>(lane & 15, rv0, rv1);
+        // Pairs of rows: the two rows end up with the same totals -- see the end of an iteration -- so the even row sends
+        // d0's value and the odd row d1's: one atomic instruction per iteration (role 0 only).  ROWS: every lane sends both.
+        int rv[2];
+        row_value_of_lane<NR>(lane & 15, rv[0], rv[1]);
         const bool odd_row = (blk & 1) != 0;
-        const int role_v = odd_row ? rv1 : rv0;
-        const int role_c = role_v >= 0 ? role_v % S : S;
-        const int role_k = role_v >= 0 && role_v < NV ? role_v / S : 0;
-        const bool role_pos = role_c == IX || role_c == IY || role_c == IW;
-        const bool role_valid = role_v >= 0 && role_v < NV && (role_c < NCHV || role_pos);
-        float* const role_base = role_pos ? grad_vertices + (role_c == IW ? 3 : role_c - IX) : grad_vertex_colors + (role_c < NCHV ? role_c : 0);
-        const uint32_t role_stride = role_pos ? gv_row_bytes : gvc_row_bytes;
+        if (!ROWS) { rv[0] = odd_row ? rv[1] : rv[0]; rv[1] = -1; }
+        constexpr int NROLES = ROWS && NR == 24 ? 2 : 1;
+        int role_k[NROLES];
+        bool role_valid[NROLES];
+        float* role_base[NROLES];
+        uint32_t role_stride[NROLES];
+#pragma unroll
+        for (int e = 0; e < NROLES; ++e) {
+            const int v = rv[e];
+            const int c = v >= 0 ? v % S : S;
+            role_k[e] = v >= 0 && v < NV ? v / S : 0;
+            const bool is_pos = c == IX || c == IY || c == IW;
+            role_valid[e] = v >= 0 && v < NV && (c < NCHV || is_pos);
+            role_base[e] = is_pos ? grad_vertices + (c == IW ? 3 : c - IX) : grad_vertex_colors + (c < NCHV ? c : 0);
+            role_stride[e] = is_pos ? gv_row_bytes : gvc_row_bytes;
+        }
         // the factors of a pixel, in pairs
         float2v fp[4][HP];
 #pragma unroll
@@ -389,7 +401,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             K = min(K, (uint32_t)__builtin_amdgcn_mov_dpp((int)K, 0x124 /* row_ror:4 */, 0xF, 0xF, true));
             K = min(K, (uint32_t)__builtin_amdgcn_mov_dpp((int)K, 0x122 /* row_ror:2 */, 0xF, 0xF, true));
             K = min(K, (uint32_t)__builtin_amdgcn_mov_dpp((int)K, 0x121 /* row_ror:1 */, 0xF, 0xF, true));
-            {   // ... and of the other row of its pair: the left (rows 0, 1) and the right (2, 3) 16 x 8 pixels of the region
+            if (!ROWS) {   // ... and of the other row of its pair: the left (rows 0, 1) and the right (2, 3) 16 x 8 pixels of the region
                 const auto sw = __builtin_amdgcn_permlane16_swap(K, K, false, false);
                 K = min(sw[0], sw[1]);
             }
@@ -398,7 +410,9 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             // the vertices this lane adds to (requested now, needed after the reduction)
             // the vertices this lane adds to (requested now, needed after the reduction)
             const uint32_t fbase = (K != NONE ? K : 0u) * 12u;
-            const int vsel = ld_off<int32_t>(faces, fbase + 4u * (uint32_t)role_k);
+            int vsel[NROLES];
+#pragma unroll
+            for (int e = 0; e < NROLES; ++e) vsel[e] = ld_off<int32_t>(faces, fbase + 4u * (uint32_t)role_k[e]);
             float2v accp[NR / 2];
 #pragma unroll
             for (int i = NV / 2; i < NR / 2; ++i) accp[i] = float2v{0.f, 0.f};
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             for (int i = 0; i < NR / 2; ++i) { acc[2 * i] = accp[i].x; acc[2 * i + 1] = accp[i].y; }
             float d0, d1;
             row_reduce_scatter<NR>(acc, lane, d0, d1);
-            {   // the two rows of a pair worked on the same face: their totals, added (both rows get the sum; the even one sends it)
+            if (!ROWS) {   // the two rows of a pair worked on the same face: their totals, added (both rows get the sum)
                 const auto s0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d0), __float_as_uint(d0), false, false);
                 d0 = __uint_as_float(s0[0]) + __uint_as_float(s0[1]);
                 if (NR == 24) {
@@ -443,20 +457,29 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                     d1 = __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
                 }
             }
-            // (a pair without a face this iteration has all-zero totals)
-            const float total = odd_row ? d1 : d0;
-            // The address is formed BEFORE the branch on purpose: the wait for the vertex index then sits on every path.
-            // Inside the branch it would leave the load pending on the path around it, and the compiler answers that
+            // (a row / pair without a face this iteration has all-zero totals)
+            float total[NROLES];
+            total[0] = ROWS ? d0 : (odd_row ? d1 : d0);
+            if (NROLES == 2) total[NROLES - 1] = d1;
+            // The addresses are formed BEFORE the branches on purpose: the wait for the vertex indices then sits on every
+            // path.  Inside a branch it would leave the load pending on the path around it, and the compiler answers that
             // with s_waitcnt vmcnt(0) in the loop header -- where it also waits, every iteration, for the previous
             // iteration's atomic to be acknowledged by the memory system (+3 us at K3, +11 us at K3-256).
-            float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(role_base) + (size_t)((uint32_t)vsel * role_stride));
-            asm volatile("" : "+v"(dst));
+            float* dst[NROLES];
+#pragma unroll
+            for (int e = 0; e < NROLES; ++e) {
+                dst[e] = reinterpret_cast<float*>(reinterpret_cast<char*>(role_base[e]) + (size_t)((uint32_t)vsel[e] * role_stride[e]));
+                asm volatile("" : "+v"(dst[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < NROLES; ++e) {
 #ifdef DIRT_GRAD_NO_ATOMICS
-            if (role_valid && total == 1.2345e-30f && vsel == -12345)   // (experiment: never true; keeps the operands alive)
+                if (role_valid[e] && total[e] == 1.2345e-30f && vsel[e] == -12345)   // (experiment: never true; keeps the operands alive)
 #else
-            if (role_valid && total != 0.f)
+                if (role_valid[e] && total[e] != 0.f)
 #endif
-                atomicAdd(dst, total);
+                    atomicAdd(dst[e], total[e]);
+            }
         }
     };
 
@@ -789,9 +812,15 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
         const dim3 grid(ntiles * (unsigned)p.npasses, (unsigned)p.B);                                           \
         if (p.debug_thingy && p.c_first == 0)                                                                   \
             hipLaunchKernelGGL((grad_kernel<SHAPE_, STRIDED_, true>), grid, block, dyn_lds, stream, p);         \
+        else if (!STRIDED_ && rows)                                                                             \
+            hipLaunchKernelGGL((grad_kernel<SHAPE_, false, false, true>), grid, block, dyn_lds, stream, p);     \
         else                                                                                                    \
             hipLaunchKernelGGL((grad_kernel<SHAPE_, STRIDED_, false>), grid, block, dyn_lds, stream, p);        \
     } while (0)
+    // every row its own face where the frame is small: at most one workgroup per CU, the float atomics have room
+    bool rows = (long long)ntiles * p.B <= 256;
+    if (p.flags & DIRT_FLAG_GRAD_ROWS) rows = true;
+    if (p.flags & DIRT_FLAG_GRAD_PAIRS) rows = false;
     p.c_first = 0; p.npasses = 1;
     // the common channel counts: kernels in which the channel count is a compile-time constant
     if (p.C == 4 && p.pixels_aligned16) DIRT_LAUNCH_GRAD(4, false);
