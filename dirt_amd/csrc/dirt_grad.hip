@@ -394,8 +394,8 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) pend[j] = (uint32_t)key[j];
         pend[4] = (uint32_t)lkey[0]; pend[5] = (uint32_t)lkey[1];
-        for (;;) {
-            // the row's next face: the smallest pending key of its 16 lanes (an all-lanes minimum by four DPP rotations)
+        // the row's next face: the smallest pending key of its 16 lanes (an all-lanes minimum by four DPP rotations)
+        auto next_face = [&]() {
             uint32_t K = min(min(min(pend[0], pend[1]), min(pend[2], pend[3])), min(pend[4], pend[5]));
             K = min(K, (uint32_t)__builtin_amdgcn_mov_dpp((int)K, 0x128 /* row_ror:8 */, 0xF, 0xF, true));
             K = min(K, (uint32_t)__builtin_amdgcn_mov_dpp((int)K, 0x124 /* row_ror:4 */, 0xF, 0xF, true));
@@ -405,6 +405,12 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                 const auto sw = __builtin_amdgcn_permlane16_swap(K, K, false, false);
                 K = min(sw[0], sw[1]);
             }
+            return K;
+        };
+        // (the loop is rotated: the next face is chosen as soon as this one's pixels are struck off the pending list, so
+        // that its chain of cross-lane minima runs alongside the reduction's chain of cross-lane adds)
+        uint32_t K = next_face();
+        for (;;) {
             const lanemask live = __builtin_amdgcn_ballot_w64(K != NONE);   // rows that still have a face
             if (live == 0ull) break;
             // the vertices this lane adds to (requested now, needed after the reduction)
@@ -444,6 +450,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                 }
             }
             GCOUNT(1, 1);
+            const uint32_t K_next = next_face();
             float acc[NR];
 #pragma unroll
             for (int i = 0; i < NR / 2; ++i) { acc[2 * i] = accp[i].x; acc[2 * i + 1] = accp[i].y; }
@@ -480,6 +487,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 #endif
                     atomicAdd(dst[e], total[e]);
             }
+            K = K_next;
         }
     };
 
