@@ -88,13 +88,12 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace {
     size_t recs_off, boxes_off, cells_off, entries_off, state_a_off, state_b_off, gv_off, gvc_off, total;
-    bool interleaved;   // the two gradient accumulators share rows of 8 floats
+    int acc_stride;     // the two gradient accumulators share rows of this many floats
 };
 
 // Layout: [FaceRec x B*F | FaceBox x B*F | chunk x bin directory | per-chunk BinEntry segments (5 per face) |
 //          float2 per-pixel state {clip_w, face} x B*H*W | float2 {b0, b1} x B*H*W | gradient accumulators:
-//          float x B*V*8 (C <= 4: a vertex's position and colour gradients in one row), or float grad_vertices x B*V*4 |
-//          float grad_vertex_colors x B*V*C]
+//          float x B*V*(4 + C rounded up to 4): a vertex's position and colour gradients in one row]
 Workspace carve(int B, int V, int F, int H, int W, int C)
 {
     Workspace w;
@@ -108,15 +107,10 @@ Workspace carve(int B, int V, int F, int H, int W, int C)
     w.state_a_off = off; off = align_up(off + (size_t)B * H * W * sizeof(float2), 256);
     w.state_b_off = off; off = align_up(off + (size_t)B * H * W * sizeof(float2), 256);
     // gradient accumulators of the backward pass, pre-cleared by a KEEP_STATE forward (dirt_state_grad_buffers):
-    // C <= 4: interleaved, one row {x, y, z, w, c0 .. c3} of 8 floats per vertex; else [B,V,4] and [B,V,C]
-    w.interleaved = C <= 4;
-    if (w.interleaved) {
-        w.gv_off = off;  w.gvc_off = off + 4 * sizeof(float);
-        off = align_up(off + (size_t)B * V * 8 * sizeof(float), 256);
-    } else {
-        w.gv_off = off;  off = align_up(off + (size_t)B * V * 4 * sizeof(float), 256);
-        w.gvc_off = off; off = align_up(off + (size_t)B * V * C * sizeof(float), 256);
-    }
+    // interleaved, one row {x, y, z, w, c0 .. cC-1} of acc_stride = 4 + C (rounded up to a multiple of 4) floats per vertex
+    w.acc_stride = (4 + C + 3) / 4 * 4;
+    w.gv_off = off;  w.gvc_off = off + 4 * sizeof(float);
+    off = align_up(off + (size_t)B * V * w.acc_stride * sizeof(float), 256);
     w.total = off + 256;
     return w;
 }
@@ -251,12 +245,7 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
     dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
     if (flags & DIRT_FLAG_KEEP_STATE) {  // pre-clear the backward pass's accumulators (dirt_state_grad_buffers)
-        if (w.interleaved) {
-            g.zero_b = c.gv;  g.zero_b_bytes = sizeof(float) * (size_t)B * V * 8;
-        } else {
-            g.zero_b = c.gv;  g.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
-            g.zero_c = c.gvc; g.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
-        }
+        g.zero_b = c.gv;  g.zero_b_bytes = sizeof(float) * (size_t)B * V * w.acc_stride;
     }
     {
         Scope sc(prof, SLOT_GEOMETRY, stream);
@@ -362,8 +351,8 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
     gp.pixels = pixels; gp.grad_pixels = grad_pixels;
     gp.grad_background = grad_background; gp.grad_vertices = grad_vertices;
     gp.grad_vertex_colors = grad_vertex_colors; gp.debug_thingy = debug_thingy;
-    gp.gv_stride = state_outputs && w.interleaved ? 8 : 4;
-    gp.gvc_stride = state_outputs && w.interleaved ? 8 : C;
+    gp.gv_stride = state_outputs ? w.acc_stride : 4;
+    gp.gvc_stride = state_outputs ? w.acc_stride : C;
     gp.B = B; gp.V = V; gp.F = F; gp.H = H; gp.W = W; gp.C = C; gp.flags = flags;
     {
         Scope sc(prof, SLOT_GRAD, stream);
@@ -386,8 +375,8 @@ int dirt_state_grad_buffers(void* workspace, size_t workspace_bytes, int B, int 
     const Carved c = carved(workspace, w);
     if (grad_vertices) *grad_vertices = c.gv;
     if (grad_vertex_colors) *grad_vertex_colors = c.gvc;
-    if (grad_vertices_row_stride) *grad_vertices_row_stride = w.interleaved ? 8 : 4;
-    if (grad_vertex_colors_row_stride) *grad_vertex_colors_row_stride = w.interleaved ? 8 : C;
+    if (grad_vertices_row_stride) *grad_vertices_row_stride = w.acc_stride;
+    if (grad_vertex_colors_row_stride) *grad_vertex_colors_row_stride = w.acc_stride;
     return DIRT_OK;
 }
 

@@ -137,10 +137,11 @@ int dirt_rasterise_visibility(const float *vertices, const int32_t *faces, int32
  * grad_vertex_colors ARE these pointers accumulates straight into them and needs no clearing launch (the reference
  * clears its outputs with four cudaMemsetAsync, csrc/rasterise_grad_egl.cu:244-250).  Any other output pointers work
  * too; they are dense ([B,V,4] and [B,V,C]) and are cleared first.
- *   For C <= 4 the two accumulators are INTERLEAVED: one row of 8 floats per vertex, {x, y, z, w, c0 .. c3}, so both
- * strides are 8 and *grad_vertex_colors == *grad_vertices + 4: a face adds its seven values per vertex to one 32-byte
- * row, which is what the memory system's float atomics are priced by (tools/atomic_bench.hip).  For C > 4 they are
- * dense: strides 4 and C.  View them as strided tensors ([B,V,4] with strides (8V, 8, 1) ...).
+ *   The two accumulators are INTERLEAVED: one row of S = 4 + C (rounded up to a multiple of 4) floats per vertex,
+ * {x, y, z, w, c0 .. cC-1}, so both strides are S and *grad_vertex_colors == *grad_vertices + 4: a face adds all of a
+ * vertex's values to one row, which is what the memory system's float atomics are priced by (tools/atomic_bench.hip).
+ * View them as strided tensors ([B,V,4] with strides (S V, S, 1) ...).  The layout depends on C: use the state's
+ * accumulators only with the channel count of the forward call that cleared them.
  */
 int dirt_state_grad_buffers(void *workspace, size_t workspace_bytes, int B, int V, int F, int H, int W, int C,
                             float **grad_vertices, float **grad_vertex_colors, int *grad_vertices_row_stride,

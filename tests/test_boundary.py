@@ -167,21 +167,17 @@ def test_scene_generators_are_deterministic():
 
 
 def test_state_gradient_accumulator_layout(lib):
-    """dirt_state_grad_buffers (ABI 2): for C <= 4 the two accumulators share rows of 8 floats (a vertex's seven values in
-    one 32-byte row: what float atomics are priced by), for C > 4 they are dense.  Host arithmetic only: no device work."""
+    """dirt_state_grad_buffers (ABI 2): the two accumulators share rows of 4 + C (rounded up to 4) floats -- all of a
+    vertex's values in one row: what float atomics are priced by.  Host arithmetic only: no device work."""
     import ctypes
     B, V, F, H, W = 2, 50, 30, 40, 24
-    for C, want in ((1, (8, 8)), (3, (8, 8)), (4, (8, 8)), (5, (4, 5)), (16, (4, 16))):
+    for C, want in ((1, 8), (3, 8), (4, 8), (5, 12), (16, 20)):
         n = lib.dirt_workspace_bytes(B, V, F, H, W, C)
         assert n > 0
         buf = np.zeros(n + 256, dtype=np.uint8)
         base = (buf.ctypes.data + 15) // 16 * 16
         gv, gvc, s1, s2 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
         assert lib.dirt_state_grad_buffers(base, n, B, V, F, H, W, C, ctypes.byref(gv), ctypes.byref(gvc), ctypes.byref(s1), ctypes.byref(s2)) == 0
-        assert (s1.value, s2.value) == want
-        assert gv.value % 16 == 0 and gvc.value % 16 == 0
-        if C <= 4:
-            assert gvc.value == gv.value + 16                       # colours 16 bytes behind the positions of the same vertex
-            assert gv.value + B * V * 32 <= base + n
-        else:
-            assert gvc.value >= gv.value + B * V * 16 and gvc.value + B * V * C * 4 <= base + n
+        assert (s1.value, s2.value) == (want, want)
+        assert gv.value % 16 == 0 and gvc.value == gv.value + 16    # colours 16 bytes behind the positions of the same vertex
+        assert gv.value + B * V * want * 4 <= base + n
