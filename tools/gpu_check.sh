@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 cd "$(dirname "$0")/.."
 {
-  echo "== permlane_test"; timeout 60 tools/_bin/permlane_test
+  echo "== reduce_test"; timeout 60 tools/_bin/reduce_test
   echo "== pytest -m gpu"; timeout ${PYTEST_TIMEOUT:-1200} python -m pytest tests -q -m gpu -x --timeout=600 2>&1 | tail -40
   for cfg in K3 K3-256 K3-2048 K5; do
     echo "== bench $cfg"; timeout 300 python bench.py --config $cfg --steps 100 --warmup 20 --no-cpu-baseline 2>&1 | tail -3

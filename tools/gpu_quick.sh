@@ -1,14 +1,16 @@
 #!/bin/bash
-# GPU session: test suite (stop at first failure), per-phase traces of grad_kernel, short bench lines.  -> gpurun_out/t.log
+# GPU session: reduction micro-test, parity tests, per-phase trace of grad_kernel, bench lines.
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 {
-  timeout 900 python -m pytest tests -q -m gpu -x --timeout=600 2>&1 | tail -${TAIL:-25}
-  if [ -f tools/_bin/libdirt_hip_trace.so ]; then
-    for c in K3 K3-2048 K3-256; do DIRT_AMD_LIBRARY=$PWD/tools/_bin/libdirt_hip_trace.so python tools/trace_grad.py $c 2>&1 | grep -v amdgpu.ids; done
-  fi
+  timeout 60 tools/_bin/reduce_test
+  ( time timeout 900 python -m pytest tests -q -m gpu -x --timeout=600 2>&1 | tail -${TAIL:-15} ) 2>&1
+  for c in ${TRACE_CONFIGS:-K3}; do
+    DIRT_AMD_LIBRARY=$PWD/tools/_bin/libdirt_hip_trace.so python tools/trace_grad.py $c 2>&1 | grep -v amdgpu.ids | head -${TRACE_HEAD:-14}
+    [ -n "$TRACE_RASTER" ] && DIRT_AMD_LIBRARY=$PWD/tools/_bin/libdirt_hip_trace.so python tools/trace_raster.py $c 2>&1 | grep -v amdgpu.ids
+  done
   for cfg in ${CONFIGS:-K3 K3-256 K3-2048 K5}; do
-    python bench.py --config $cfg --steps 100 --warmup 20 --no-cpu-baseline 2>&1 | python -c "
+    python bench.py --config $cfg --steps 200 --warmup 50 --no-cpu-baseline 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

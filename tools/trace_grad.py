@@ -1,4 +1,4 @@
-"""Per-wave phase timing of grad_kernel (tracing build of the library: -DDIRT_TRACE, see tools/trace_grad.sh).
+"""Per-wave phase timing of grad_kernel (tracing build of the library: -DDIRT_TRACE, see tools/build_tools.sh).
 usage: python tools/trace_grad.py [config]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""Per-wave phase timing of raster_kernel (tracing build of the library: -DDIRT_TRACE, tools/trace_grad.sh builds it).
+"""Per-wave phase timing of raster_kernel (tracing build of the library: -DDIRT_TRACE, tools/build_tools.sh builds it).
 usage: python tools/trace_raster.py [config]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
