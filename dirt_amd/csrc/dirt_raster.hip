@@ -172,8 +172,7 @@ __global__ __launch_bounds__(STHREADS) void setup_kernel(GeomParams g)
 // NB = 2 (32 x 32 tiles, one record fetch serves 256 pixels) is the normal shape; NB = 1 (16 x 16 tiles) gives four
 // times as many workgroups for small frames, where 32 x 32 tiles would leave most of the 1024 SIMDs idle.
 constexpr int RTHREADS = 256;     // 4 waves: one per region
-constexpr int LIST_CAP = 1024;    // candidates listed per round: four segments, one per wave
-constexpr int SEG_CAP = LIST_CAP / 4;
+constexpr int LIST_CAP = 1024;    // candidates listed per round
 constexpr int SHADE_CAP = 96;     // candidates whose set-up record (and vertex colours) stay in LDS for the shading pass
 
 // What the coverage / depth loop reads per candidate: built once per (tile, candidate) by one lane when the
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
     constexpr bool LDS_COLORS = MODE == 0 && CSPEC != 0;
     __shared__ int32_t s_face[LIST_CAP];
     __shared__ uint16_t s_mask[LIST_CAP];  // bit (BT*by + bx): the face's box touches block (bx, by) of the tile
-    __shared__ uint32_t s_cnt[4];          // entries in each wave's segment of the list
+    __shared__ uint32_t s_count;
     __shared__ TileRec s_rec[64];          // tile-local records of the 64 list entries being rasterised
     __shared__ FaceRec s_shade[SHADE_CAP]; // the set-up records of the first listed candidates, for the shading pass
     __shared__ float4 s_col[LDS_COLORS ? SHADE_CAP : 1][3];  // ... and their vertex colours (channel-specialised kernels)
@@ -387,8 +386,8 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
 
     TRACE_MARK();  // 1: directory requested
     for (int round = 0;; ++round) {
-        // every wave appends to its own segment of the list: its counter needs no barrier (the LDS serves a wave in order)
-        if (lane == 0) s_cnt[wave] = 0;
+        if (tid == 0) s_count = 0;
+        __syncthreads();
         TRACE_MARK();  // 2: cleared, barrier
         // ---- scan: this thread's runs, four entries per trip ----
         bool full = false;
@@ -407,15 +406,15 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
                     if (run_pos[k] >= run_count[k] || full) break;
                     const FaceBox box = en[i].box;
                     if (box.i_min <= tx1 && box.i_max >= tx0 && box.r_min <= tr1 && box.r_max >= tr0) {
-                        const uint32_t slot = atomicAdd(&s_cnt[wave], 1u);
-                        if (slot >= (uint32_t)SEG_CAP) { full = true; break; }   // not consumed: next round
+                        const uint32_t slot = atomicAdd(&s_count, 1u);
+                        if (slot >= (uint32_t)LIST_CAP) { full = true; break; }   // not consumed: next round
                         const int bx0 = max(box.i_min - tx0, 0) >> 3, bx1 = min(box.i_max - tx0, TILE - 1) >> 3;
                         const int by0 = max(box.r_min - tr0, 0) >> 3, by1 = min(box.r_max - tr0, TILE - 1) >> 3;
                         const uint32_t rowbits = ((2u << bx1) - (1u << bx0)) & ((1u << BT) - 1u);
                         uint32_t mask = 0;
                         for (int by = by0; by <= by1; ++by) mask |= rowbits << (BT * by);
-                        s_face[wave * SEG_CAP + slot] = en[i].face;
-                        s_mask[wave * SEG_CAP + slot] = (uint16_t)mask;
+                        s_face[slot] = en[i].face;
+                        s_mask[slot] = (uint16_t)mask;
                         // the staging pass reads this face's set-up record (one 128-byte line, written by another XCD's
                         // set-up workgroup) after the list barrier: touch it now, so that it is on its way to this
                         // XCD's L2 while the list is still being built.  The loaded word is never used; `touch` stays
@@ -429,13 +428,7 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
         TRACE_MARK();  // 3: appended
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch));
         __syncthreads();
-        // the list: the four segments one after the other
-        const int n0 = (int)min(s_cnt[0], (uint32_t)SEG_CAP), n1 = (int)min(s_cnt[1], (uint32_t)SEG_CAP);
-        const int n2 = (int)min(s_cnt[2], (uint32_t)SEG_CAP), n3 = (int)min(s_cnt[3], (uint32_t)SEG_CAP);
-        const int p1 = n0, p2 = n0 + n1, p3 = n0 + n1 + n2, n = p3 + n3;
-        auto slot_of = [&](int i) {   // list index -> position in s_face / s_mask
-            return i < p1 ? i : (i < p2 ? SEG_CAP + i - p1 : (i < p3 ? 2 * SEG_CAP + i - p2 : 3 * SEG_CAP + i - p3));
-        };
+        const int n = (int)min(s_count, (uint32_t)LIST_CAP);
         if (round != 0) lds_records = false;
         TRACE_MARK();  // 4: list built
 
@@ -449,7 +442,7 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
             float4 colv0 = make_float4(0.f, 0.f, 0.f, 0.f), colv1 = colv0, colv2 = colv0;
             bool stage_colors = false;
             if (tid < m_chunk) {
-                const int face = s_face[slot_of(cb + tid)];
+                const int face = s_face[cb + tid];
                 const FaceRec rec = recs[face];
                 make_tile_rec(rec, face, (double)tx0 + 0.5, (double)(p.H - 1 - tr0) + 0.5, wf, hf, &s_rec[tid]);
                 if (round == 0 && cb + tid < SHADE_CAP) {
@@ -472,7 +465,7 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
             const int idx = cb + lane;
             uint32_t mym4 = 0;
             if (idx < n) {
-                const uint32_t mk = s_mask[slot_of(idx)];
+                const uint32_t mk = s_mask[idx];
                 // the wave's block bits inside the tile mask, gathered into NB * NB bits (NB * by + bx)
 #pragma unroll
                 for (int by = 0; by < NB; ++by)
