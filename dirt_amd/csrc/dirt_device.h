@@ -62,6 +62,7 @@ __device__ inline bool setup_face(const float* __restrict__ verts, int V, const 
     vv[1] = *reinterpret_cast<const float4*>(verts + (size_t)((uint32_t)i1 < (uint32_t)V ? i1 : 0) * 4);
     vv[2] = *reinterpret_cast<const float4*>(verts + (size_t)((uint32_t)i2 < (uint32_t)V ? i2 : 0) * 4);
     if (!index_ok) return false;
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int32_t vi = k == 0 ? i0 : (k == 1 ? i1 : i2);
         const float4 v = vv[k];
@@ -73,6 +74,7 @@ __device__ inline bool setup_face(const float* __restrict__ verts, int V, const 
         rec.vid[k] = vi;
     }
     double a[3], b[3], c[3];
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int p = (k + 1) % 3, q = (k + 2) % 3;
         double m1, m2;
@@ -84,6 +86,7 @@ __device__ inline bool setup_face(const float* __restrict__ verts, int V, const 
     double det = (t0 + t1) + t2;
     if (!isfinite(det) || det == 0.0) return false;
     if (det < 0.0) {
+#pragma unroll
         for (int k = 0; k < 3; ++k) { a[k] = -a[k]; b[k] = -b[k]; c[k] = -c[k]; }
         det = -det;
     }
@@ -101,6 +104,7 @@ __device__ inline bool setup_face(const float* __restrict__ verts, int V, const 
         // conservative: float rounding (2^-22 relative on |x| <= 32768 px) is covered by the 1/32 px margin,
         // anything larger is outside the frame on that side anyway.
         float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float rw = 1.0f / (float)Wc[k];
             float xw = (float)X[k] * rw, yw = (float)Y[k] * rw;
@@ -123,6 +127,7 @@ __device__ inline bool setup_face(const float* __restrict__ verts, int V, const 
 
     // depth plane from the unfolded coefficients (NDC depth = sum_k E_k * z_k / det is affine in the sample)
     double zs[3];
+#pragma unroll
     for (int k = 0; k < 3; ++k) zs[k] = Z[k] * inv_det;
     {
         double m0, m1, m2;
@@ -131,6 +136,7 @@ __device__ inline bool setup_face(const float* __restrict__ verts, int V, const 
         m0 = c[0] * zs[0]; m1 = c[1] * zs[1]; m2 = c[2] * zs[2]; rec.zp[2] = fma((m0 + m1) + m2, 8388607.5, 8388607.5);
     }
     uint32_t flags = FACE_VALID;
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
         const bool incl = (a[k] > 0.0) || (a[k] == 0.0 && b[k] > 0.0);
         if (!incl) { a[k] = -a[k]; b[k] = -b[k]; c[k] = -c[k]; flags |= (1u << k); }

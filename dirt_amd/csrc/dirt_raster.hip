@@ -61,20 +61,24 @@ __global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ b, siz
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += stride) c[i] = 0u;
 }
 
-constexpr int STHREADS = 64;   // one wave per chunk: ~160 workgroups for 10 000 faces, and no barrier between its phases but LDS order
+constexpr int STHREADS = 64;   // one wave per chunk of <= 64 faces: ~160 workgroups for 10 000 faces, and no barrier between its phases
+                               // but LDS order; NW = 4 waves per chunk for larger chunks (meshes of more than 16 384 faces: a
+                               // thread still owns one face, where a single wave would walk its chunk in several trips)
 
-__global__ __launch_bounds__(STHREADS) void setup_kernel(GeomParams g)
+template <int NW>
+__global__ __launch_bounds__(STHREADS * NW) void setup_kernel(GeomParams g)
 {
+    constexpr int NT = STHREADS * NW;
     __shared__ uint32_t s_cnt[MAX_BINS + 1];    // [MAX_BINS] = big faces
     __shared__ uint32_t s_start[MAX_BINS + 1];  // exclusive prefix of s_cnt = the chunk's segment layout
-    const int ib = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
+    const int ib = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x & 63, tid = threadIdx.x;
     // side job: clear the gradient accumulators of the backward pass (the cudaMemsetAsync x4 of
     // csrc/rasterise_grad_egl.cu:244-250) so that no separate launch is needed for it
     {
         // 16 bytes per store (the buffers are 16-byte aligned and their sizes multiples of 16: [B,V,4] floats and the
         // 256-byte aligned workspace regions; caller tensors of other sizes get a dword tail)
-        const size_t nthreads = (size_t)gridDim.x * gridDim.y * STHREADS;
-        const size_t gtid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * STHREADS + lane;
+        const size_t nthreads = (size_t)gridDim.x * gridDim.y * NT;
+        const size_t gtid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NT + tid;
         uint4* zb = reinterpret_cast<uint4*>(g.zero_b);
         uint4* zc = reinterpret_cast<uint4*>(g.zero_c);
         const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
@@ -86,9 +90,7 @@ __global__ __launch_bounds__(STHREADS) void setup_kernel(GeomParams g)
         if (gtid < (g.zero_c_bytes % 16) / 4) tc[gtid] = 0u;
     }
     static_assert(MAX_BINS == 4 * STHREADS, "four bins per lane");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s_cnt[4 * lane + i] = 0;
-    if (lane == 0) s_cnt[MAX_BINS] = 0;
+    for (int i = tid; i <= MAX_BINS; i += NT) s_cnt[i] = 0;
     __syncthreads();
     const int f0 = chunk * g.chunk_faces, f1 = min(g.F, f0 + g.chunk_faces);
     const float* __restrict__ verts = g.vertices + (size_t)ib * g.V * 4;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(STHREADS) void setup_kernel(GeomParams g)
     // ---- pass 1: set-up + histogram ----
     FaceBox first_box;  // the box of this thread's first face stays in registers for pass 2
     first_box.i_min = 32767; first_box.i_max = -32768; first_box.r_min = 32767; first_box.r_max = -32768;
-    for (int f = f0 + lane; f < f1; f += STHREADS) {
+    for (int f = f0 + tid; f < f1; f += NT) {
         const size_t n = (size_t)ib * g.F + f;
         FaceRec rec;
         FaceBox box;
@@ -113,46 +115,46 @@ __global__ __launch_bounds__(STHREADS) void setup_kernel(GeomParams g)
             g.recs[n].flags = 0;
             box.i_min = 32767; box.i_max = -32768; box.r_min = 32767; box.r_max = -32768;
         }
-        if (f == f0 + lane) first_box = box;
-        if (g.chunk_faces > STHREADS) g.boxes[n] = box;  // re-read in pass 2 when a thread owns several faces
+        if (f == f0 + tid) first_box = box;
+        if (g.chunk_faces > NT) g.boxes[n] = box;  // re-read in pass 2 when a thread owns several faces
     }
     __syncthreads();
 
-    // ---- the chunk's segment layout: exclusive prefix over the 257 (pseudo-)bins, four bins per lane ----
-    uint32_t cnt[4], sum = 0;
+    // ---- the chunk's segment layout: exclusive prefix over the 257 (pseudo-)bins, four bins per lane of the first wave ----
+    if (tid < STHREADS) {
+        uint32_t cnt[4], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { cnt[i] = s_cnt[4 * lane + i]; sum += cnt[i]; }
-    uint32_t incl = sum;
+        for (int i = 0; i < 4; ++i) { cnt[i] = s_cnt[4 * lane + i]; sum += cnt[i]; }
+        uint32_t incl = sum;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
-    uint32_t start = incl - sum;
-    // the directory is stored bin-major, [bin][chunk]: what a raster tile reads -- its bin's cell of every chunk -- is
-    // then contiguous (nchunk x 8 bytes = a few lines, instead of one line per chunk)
-    BinCell* __restrict__ col = g.cells + (size_t)ib * (MAX_BINS + 1) * g.nchunk + chunk;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        uint32_t start = incl - sum;
+        // the directory is stored bin-major, [bin][chunk]: what a raster tile reads -- its bin's cell of every chunk -- is
+        // then contiguous (nchunk x 8 bytes = a few lines, instead of one line per chunk)
+        BinCell* __restrict__ col = g.cells + (size_t)ib * (MAX_BINS + 1) * g.nchunk + chunk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        s_start[4 * lane + i] = start;
-        col[(size_t)(4 * lane + i) * g.nchunk] = BinCell{start, cnt[i]};
-        start += cnt[i];
-    }
-    if (lane == STHREADS - 1) {
-        s_start[MAX_BINS] = start;
-        col[(size_t)MAX_BINS * g.nchunk] = BinCell{start, s_cnt[MAX_BINS]};
+        for (int i = 0; i < 4; ++i) {
+            s_start[4 * lane + i] = start;
+            col[(size_t)(4 * lane + i) * g.nchunk] = BinCell{start, cnt[i]};
+            start += cnt[i];
+        }
+        if (lane == STHREADS - 1) {
+            s_start[MAX_BINS] = start;
+            col[(size_t)MAX_BINS * g.nchunk] = BinCell{start, s_cnt[MAX_BINS]};
+        }
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s_cnt[4 * lane + i] = 0;  // reused as the fill cursors
-    if (lane == 0) s_cnt[MAX_BINS] = 0;
+    for (int i = tid; i <= MAX_BINS; i += NT) s_cnt[i] = 0;  // reused as the fill cursors
     __syncthreads();
 
     // ---- pass 2: faces claim their slots in the chunk's segment ----
     BinEntry* __restrict__ out = g.entries + ((size_t)ib * g.nchunk + chunk) * (5 * (size_t)g.chunk_faces);
-    for (int f = f0 + lane; f < f1; f += STHREADS) {
+    for (int f = f0 + tid; f < f1; f += NT) {
         BinEntry e;
-        e.box = (f == f0 + lane) ? first_box : g.boxes[(size_t)ib * g.F + f];
+        e.box = (f == f0 + tid) ? first_box : g.boxes[(size_t)ib * g.F + f];
         if (e.box.i_min > e.box.i_max) continue;  // culled at set-up
         e.face = f; e.pad = 0;
         int bx0, bx1, by0, by1;
@@ -641,7 +643,8 @@ hipError_t launch_geometry(const GeomParams& g, hipStream_t stream)
     if (g.B == 0) return hipSuccess;
     // also with F == 0: the (all-zero) directory row is what the raster kernel reads
     const dim3 grid((unsigned)g.nchunk, (unsigned)g.B);
-    hipLaunchKernelGGL(setup_kernel, grid, dim3(STHREADS), 0, stream, g);
+    if (g.chunk_faces > STHREADS) hipLaunchKernelGGL(setup_kernel<4>, grid, dim3(4 * STHREADS), 0, stream, g);
+    else hipLaunchKernelGGL(setup_kernel<1>, grid, dim3(STHREADS), 0, stream, g);
     return hipGetLastError();
 }
 

@@ -25,6 +25,8 @@ def slot(kernel):
         return 'grad_kernel'
     if kernel.startswith('raster_kernel<0'):
         return 'raster_kernel<shade>'
+    if kernel.startswith('setup_kernel'):
+        return 'setup_kernel'
     if kernel.startswith('raster_kernel<1'):
         return 'raster_kernel<visibility>'
     return kernel
