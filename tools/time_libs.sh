@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 CONFIGS=$1; shift
 for v in "$@"; do
   for cfg in $CONFIGS; do
-    DIRT_AMD_LIBRARY=$PWD/tools/_bin/$v.so python bench.py --config $cfg --steps 200 --warmup 50 --no-cpu-baseline --launch eager 2>&1 | python -c "
+    DIRT_AMD_LIBRARY=$PWD/tools/_bin/$v.so python bench.py $BENCH_ARGS --config $cfg --steps 200 --warmup 50 --no-cpu-baseline --launch eager 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
