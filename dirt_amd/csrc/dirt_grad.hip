@@ -330,9 +330,9 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 
     // (fx, fy) sent to this strip's own pixels by themselves (see "position factors" below)
     using std::integral_constant;
-    float fxy[4][2];
+    float2v fxy[4];   // (as pairs: what the face loop multiplies is then already in place)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { fxy[j][0] = 0.f; fxy[j][1] = 0.f; }
+    for (int j = 0; j < 4; ++j) fxy[j] = float2v{0.f, 0.f};
 
     // ---- the face loop.  Every DPP row of the wave (16 lanes = an 8 x 8 pixel block) walks the distinct faces among its
     //      pixels (key[j], -1 = none) and among the ring cells its lanes hold (lkey), all four rows at once: an iteration
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     //      instructions add the four faces' totals to their vertices.  A block sees ~3 faces where the 16 x 8 half
     //      regions of the two-group version saw ~6. ----
     auto face_loop = [&](auto nchv_tag, const auto& g, const int (&key)[4], const bool (&covered)[4],
-                         const float (&fpos)[4][3], const int (&lkey)[2], const float (&lb)[2][3], const float (&lf)[2][3]) {
+                         const float2v (&fpos_xy)[4], const float (&fpos_w)[4], const int (&lkey)[2], const float (&lb)[2][3], const float (&lf)[2][3]) {
         constexpr int NCHV = decltype(nchv_tag)::value;
         constexpr int S = (3 + NCHV + 1) & ~1;      // values per vertex (padded to whole pairs)
         constexpr int HP = S / 2;                   // ... as pairs
@@ -384,9 +384,10 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             float f[S];
 #pragma unroll
             for (int c = 0; c < S; ++c) f[c] = c < NCHV ? g[j][c < NCHV ? c : 0] : 0.f;
-            f[IX] = fpos[j][0]; f[IY] = fpos[j][1]; f[IW] = fpos[j][2];
+            f[IW] = fpos_w[j];
 #pragma unroll
             for (int h = 0; h < HP; ++h) { fp[j][h].x = f[2 * h]; fp[j][h].y = f[2 * h + 1]; }
+            fp[j][IX / 2] = fpos_xy[j];
         }
         // pending faces: the keys of this lane's pixels / ring cells not yet added (NONE: none or done; "no face" is -1 = NONE)
         constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -495,15 +496,15 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     //      totals) and the ring: what this wave's pixels sent to pixels of other waves (the row above / below the region,
     //      the column left / right of the tile).  Those pixels' faces take it through the face loop, at most two ring
     //      cells per lane: cells 0-33 the row above, 34-67 the row below, 68-75 / 76-83 the columns left / right. ----
-    auto gather_positions = [&](float (&fpos)[4][3], int (&lkey)[2], float (&lb)[2][3], float (&lf)[2][3]) {
+    auto gather_positions = [&](float2v (&fpos_xy)[4], float (&fpos_w)[4], int (&lkey)[2], float (&lb)[2][3], float (&lf)[2][3]) {
         const float4 i01 = *reinterpret_cast<const float4*>(inbox + my_cell), i23 = *reinterpret_cast<const float4*>(inbox + my_cell + 2);
-        fpos[0][0] = fxy[0][0] + i01.x; fpos[0][1] = fxy[0][1] + i01.y; fpos[1][0] = fxy[1][0] + i01.z; fpos[1][1] = fxy[1][1] + i01.w;
-        fpos[2][0] = fxy[2][0] + i23.x; fpos[2][1] = fxy[2][1] + i23.y; fpos[3][0] = fxy[3][0] + i23.z; fpos[3][1] = fxy[3][1] + i23.w;
-        const float ndc_y_own = ((float)(H - 1 - y) + 0.5f) * (2.f / height_f) - 1.f;
+        fpos_xy[0] = fxy[0] + float2v{i01.x, i01.y}; fpos_xy[1] = fxy[1] + float2v{i01.z, i01.w};
+        fpos_xy[2] = fxy[2] + float2v{i23.x, i23.y}; fpos_xy[3] = fxy[3] + float2v{i23.z, i23.w};
+        const float ndc_y_own = ((float)(H - 1 - y) + 0.5f) * p.two_over_h - 1.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float ndc_x = ((float)(xs + j) + 0.5f) * (2.f / width_f) - 1.f;
-            fpos[j][2] = -(fpos[j][0] * ndc_x + fpos[j][1] * ndc_y_own);
+            const float ndc_x = ((float)(xs + j) + 0.5f) * p.two_over_w - 1.f;
+            fpos_w[j] = -(fpos_xy[j].x * ndc_x + fpos_xy[j].y * ndc_y_own);
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -520,8 +521,8 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                     lkey[e] = __float_as_int(s_vw[8 * wave + ty + 1][tx + 2].y);
                     const float2 nb = ld_off<float2>(state_b, (uint32_t)((py - row0) * W + px) * 8u);
                     lb[e][0] = nb.x; lb[e][1] = nb.y; lb[e][2] = (1.f - nb.x) - nb.y;
-                    const float ndc_x = ((float)px + 0.5f) * (2.f / width_f) - 1.f;
-                    const float ndc_y = ((float)(H - 1 - py) + 0.5f) * (2.f / height_f) - 1.f;
+                    const float ndc_x = ((float)px + 0.5f) * p.two_over_w - 1.f;
+                    const float ndc_y = ((float)(H - 1 - py) + 0.5f) * p.two_over_h - 1.f;
                     lf[e][0] = v.x; lf[e][1] = v.y; lf[e][2] = -(v.x * ndc_x + v.y * ndc_y);
                 }
             }
@@ -768,8 +769,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                 const float dLx_j = (j & 1) ? dLx[gi][j >> 1].y : dLx[gi][j >> 1].x, dLy_j = (j & 1) ? dLy[gi][j >> 1].y : dLy[gi][j >> 1].x;
                 float2v f = (float2v{dLx_j, dLy_j} * half_size) * float2v{rcp_w, rcp_w};
                 const bool own = __builtin_amdgcn_inverse_ballot_w64(m_cov & ~dil);   // contributes to its own pixel
-                fxy[j][0] += own ? f.x : 0.f;
-                fxy[j][1] += own ? f.y : 0.f;
+                fxy[j] += float2v{own ? f.x : 0.f, own ? f.y : 0.f};
                 if (dilated) {  // few lanes: ds_add_f32 into the neighbour's cell
                     const int step = __builtin_amdgcn_inverse_ballot_w64(hz) ? 1 : -IS;   // +x, or up = the previous row
                     float* cell = reinterpret_cast<float*>(inbox + (my_cell + j + (__builtin_amdgcn_inverse_ballot_w64(fwd) ? step : -step)));
@@ -780,12 +780,13 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         }
         GMARK();  // 5 dilation done
         // positions and colours in one face loop
-        float fpos[4][3];
+        float2v fpos_xy[4];
+        float fpos_w[4];
         int lkey[2];
         float lb[2][3], lf[2][3];
-        gather_positions(fpos, lkey, lb, lf);
+        gather_positions(fpos_xy, fpos_w, lkey, lb, lf);
         GMARK();  // 6 face loop starts
-        face_loop(integral_constant<int, NCH>{}, g, key, covered, fpos, lkey, lb, lf);
+        face_loop(integral_constant<int, NCH>{}, g, key, covered, fpos_xy, fpos_w, lkey, lb, lf);
     };
 
     run_pass(integral_constant<int, CSPEC>{}, integral_constant<int, CSPEC == 1 ? 1 : 3>{});
@@ -806,6 +807,7 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     GradParams p = p_in;
     p.tiles_x = (p.W + GT - 1) / GT;
     p.tiles_y = (p.H + GT - 1) / GT;
+    p.two_over_w = 2.f / (float)p.W; p.two_over_h = 2.f / (float)p.H;   // (IEEE divisions, as the kernel's own would be)
     p.pixels_aligned16 = ((reinterpret_cast<uintptr_t>(p.pixels) | reinterpret_cast<uintptr_t>(p.grad_pixels) |
                            reinterpret_cast<uintptr_t>(p.grad_background)) & 15u) == 0 ? 1 : 0;
 #ifdef DIRT_TRACE

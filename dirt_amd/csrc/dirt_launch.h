@@ -80,6 +80,7 @@ struct GradParams {
     int tiles_x, tiles_y;      // filled by launch_grad
     int pixels_aligned16;      // the [B,H,W,C] tensors may be accessed with 16-byte loads / stores, filled by launch_grad
     int c_first, npasses;      // the launch's channel passes (see grad_kernel<CSPEC, STRIDED>), filled by launch_grad
+    float two_over_w, two_over_h;  // 2 / W, 2 / H (pixel -> NDC), filled by launch_grad
 };
 
 BinGrid make_bin_grid(int H, int W);
