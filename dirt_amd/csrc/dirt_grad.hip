@@ -78,7 +78,7 @@ __device__ __forceinline__ float2v pk_mul_scalar(float s, float2v b)
 
 constexpr int GT = 32;                  // tile side (pixels)
 constexpr int GTHREADS = 256;           // 4 waves: wave w owns rows 8w .. 8w+7; a DPP row of 16 lanes owns an 8 x 8 block of them
-                                        // (block l >> 4), lane l the strip x = 8 * (l >> 4) + 4 * (l & 1) .. +3 of row (l >> 1) & 7
+                                        // (block l >> 4), a lane a 4 x 1 strip of it
 constexpr int PR = GT + 2;              // staged rows: y0-1 .. y0+32
 constexpr int PS = 36;                  // plane row stride (floats): column (x - x0) + 1 for x0-1 .. x0+34, so that a strip's taps start
                                         // (with the column left of it) at a 16-byte boundary
@@ -234,7 +234,10 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 
     // ---- this lane's strip ----
     const int blk = lane >> 4;                  // the lane's DPP row = its 8 x 8 block of the wave's region
-    const int sx = 2 * blk + (lane & 1), ry = (lane >> 1) & 7;
+    // (which lane of the row takes which strip is free; this assignment -- strip: lane bit 2; row: bits 3, 0, 1 -- is the one
+    // whose 16-byte LDS reads of the planes, the state tile and the inbox collide least: 8 / 16 / 16 LDS cycles per wave
+    // instruction against 12 / 32 / 24 for the plain order, by the lane groups of the guide's LDS table)
+    const int sx = 2 * blk + ((lane >> 2) & 1), ry = ((lane >> 3) & 1) | ((lane & 1) << 1) | (((lane >> 1) & 1) << 2);
     const int xs = x0 + 4 * sx;                 // first pixel of the strip
     const int y = y0 + 8 * wave + ry;           // tensor row (top row first)
     const int hr = 8 * wave + ry + 1;           // its row in the halo'd tile
