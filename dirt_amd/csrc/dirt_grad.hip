@@ -201,13 +201,18 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     const int H = p.H, W = p.W, C = STRIDED ? p.C : CSPEC;
     const size_t frame = (size_t)H * W;
     // this workgroup's tile and pass: CSPEC channels starting at channel cbase
+    // (STRIDED, CSPEC = 4: the launch's passes are 3-channel groups, and only the LAST of them also carries the single that
+    // follows the triples -- single_on, wave-uniform.  All passes of an image then go out in one launch and meet in the
+    // L2: a pass launched on its own fetches every 64-byte pixel for 4-16 bytes of it, K5: 245 us instead of ~100)
     int tile, cbase = 0;
+    bool single_on = true;
     if constexpr (!STRIDED) {
         tile = xcd_tile((int)blockIdx.x, p.tiles_x * p.tiles_y);
     } else {
         const int item = xcd_tile((int)blockIdx.x, p.tiles_x * p.tiles_y * p.npasses);
         tile = item / p.npasses;
         cbase = p.c_first + (item - tile * p.npasses) * (CSPEC == 1 ? 1 : 3);
+        single_on = CSPEC != 4 || item - tile * p.npasses == p.npasses - 1;
     }
     const bool aligned16 = (!STRIDED && CSPEC == 4) ? true : (p.pixels_aligned16 != 0 && (cbase & 3) == 0);
     const int x0 = (tile % p.tiles_x) * GT, y0 = (tile / p.tiles_x) * GT;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     //      Halo positions outside the frame are clamped; they are only ever consulted for interior pixels, whose
     //      neighbours are inside the frame. ----
     float stage_v[PITEMS][PC];
-    stage_load(CSPEC, stage_v);
+    stage_load(single_on ? CSPEC : 3, stage_v);
     {
         // (the same sweep: column x0 - 1 + tid % 34, rows tid / 34, + 7, ...; threads 238 .. 255 idle)
         constexpr int VITEMS = (PR + PROWS - 1) / PROWS;
@@ -549,9 +554,13 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             const uint32_t off = in_px[j] ? own_off + (uint32_t)j * pixel_bytes : 0u;  // outside the frame: any valid address
             bool wide = false;
             if constexpr (NCH == 4) {
-                if ((C & 3) == 0 && aligned16) {
+                if (single_on && (C & 3) == 0 && aligned16) {
                     const float4 q = ld_off<float4>(gpix_t, off);
                     g[j][0] = q.x; g[j][1] = q.y; g[j][2] = q.z; g[j][3] = q.w;
+                    wide = true;
+                } else if (!single_on) {
+                    const Float3 q = ld_off<Float3>(gpix_t, off);
+                    g[j][0] = q.x; g[j][1] = q.y; g[j][2] = q.z; g[j][3] = 0.f;   // (a zero fourth channel adds nothing anywhere)
                     wide = true;
                 }
             }
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             }
         }
         GMARK();  // 1 loads issued, state tile stored
-        stage_store(NCH, stage_v);
+        stage_store(single_on ? NCH : 3, stage_v);
         GMARK();  // 2 planes stored
         __syncthreads();
         GMARK();  // 3 barrier passed
@@ -588,6 +597,12 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                 const int gi = ch < G0 ? 0 : ch - G0 + 1;     // the channel's group
                 const bool single = !(ch < G0 && G0 == 3);     // a 1-channel group: quirk Q1 applies
                 const bool last_of_group = single || ch == G0 - 1;
+                if (STRIDED && NCH == 4 && ch == 3 && !single_on) {   // a pass without the single: nothing of group 1 is used
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) horiz_m[gi][j] = 0ull;
+                    dLx[gi][0] = dLx[gi][1] = dLy[gi][0] = dLy[gi][1] = float2v{0.f, 0.f};
+                    continue;
+                }
                 // taps of row r as pairs: T[r][i] = columns (xs - 1 + 2i, xs + 2i); a 3-channel group needs columns
                 // xs-1 .. xs+4 (three pairs), a single xs-1 .. xs+6 (its aliased "channels" are the next two pixels)
                 constexpr int NT = 4;
@@ -711,8 +726,11 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             const uint32_t off = own_off + (uint32_t)j * pixel_bytes;
             bool wide = false;
             if constexpr (NCH == 4) {
-                if ((C & 3) == 0 && aligned16) {
+                if (single_on && (C & 3) == 0 && aligned16) {
                     st_off<float4>(gbk_t, off, covered[j] ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(g[j][0], g[j][1], g[j][2], g[j][3]));
+                    wide = true;
+                } else if (!single_on) {
+                    st_off<Float3>(gbk_t, off, covered[j] ? Float3{0.f, 0.f, 0.f} : Float3{g[j][0], g[j][1], g[j][2]});
                     wide = true;
                 }
             }
@@ -752,6 +770,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             const lanemask pos = (j & 1) ? ~parity0 : parity0;   // first attempt towards +x / up (:191), else -x / down
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
+                if (STRIDED && NCH == 4 && gi == 1 && !single_on) continue;
                 // direction: x if L1(Sx) > L1(Sy) else y (:185), negated on odd (x + y) (:186-190).  The reference's
                 // offsets are in GL buffer orientation (y up): tensor row = y - offset_y.
                 const lanemask hz = horiz_m[gi][j];
@@ -841,12 +860,18 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     else if (p.C == 1) DIRT_LAUNCH_GRAD(1, false);
     else {
         // any other channel count: passes of whole channel groups (groups of 3 while >= 3 channels remain, then singles,
-        // dirt/rasterise_ops.py:148-152); the last 3-group and the first single share a pass.  One launch per pass shape.
+        // dirt/rasterise_ops.py:148-152).  Every 3-channel pass goes out in ONE launch -- of the {3,1} body when a single
+        // follows the triples: its last pass carries that single, the others switch the single's parts off -- so that the
+        // passes of a tile meet in the L2 (a second single, C % 3 == 2, is a launch of its own).
         const int groups3 = p.C / 3, singles = p.C % 3;
-        const int has4 = (groups3 >= 1 && singles >= 1) ? 1 : 0;
-        if (groups3 - has4 > 0) { p.c_first = 0; p.npasses = groups3 - has4; DIRT_LAUNCH_GRAD(3, true); }
-        if (has4) { p.c_first = 3 * (groups3 - 1); p.npasses = 1; DIRT_LAUNCH_GRAD(4, true); }
-        if (singles - has4 > 0) { p.c_first = 3 * groups3 + has4; p.npasses = singles - has4; DIRT_LAUNCH_GRAD(1, true); }
+        if (groups3 >= 1 && singles >= 1) {
+            p.c_first = 0; p.npasses = groups3; DIRT_LAUNCH_GRAD(4, true);
+            if (singles == 2) { p.c_first = 3 * groups3 + 1; p.npasses = 1; DIRT_LAUNCH_GRAD(1, true); }
+        } else if (groups3 >= 1) {
+            p.c_first = 0; p.npasses = groups3; DIRT_LAUNCH_GRAD(3, true);
+        } else {
+            p.c_first = 0; p.npasses = singles; DIRT_LAUNCH_GRAD(1, true);
+        }
     }
 #undef DIRT_LAUNCH_GRAD
     return hipGetLastError();
