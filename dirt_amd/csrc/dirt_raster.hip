@@ -320,6 +320,10 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
     __shared__ TileRec s_rec[64];          // tile-local records of the 64 list entries being rasterised
     __shared__ FaceRec s_shade[SHADE_CAP]; // the set-up records of the first listed candidates, for the shading pass
     __shared__ float4 s_col[LDS_COLORS ? SHADE_CAP : 1][3];  // ... and their vertex colours (channel-specialised kernels)
+    // any channel count that is a multiple of 4, up to 16: the colours of the first QCAP listed candidates, [candidate][vertex][quad]
+    constexpr bool LDS_QUADS = MODE == 0 && CSPEC == 0;
+    constexpr int QCAP = 48;
+    __shared__ float4 s_colq[LDS_QUADS ? QCAP * 3 * 4 : 1];
 
 #ifdef DIRT_TRACE
     long long tr_t[8]; int tr_n = 0;
@@ -385,6 +389,7 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
 #pragma unroll
     for (int k = 0; k < PPL; ++k) { zbest[k] = Z24_CLEAR; fbest[k] = -1; cbest[k] = SHADE_CAP; }  // -1: a tie with the cleared depth never wins
     bool lds_records = true;   // false once a second round has reused the list (dense meshes): records come from memory then
+    int n_first = 0;           // candidates listed in the first round
 
     TRACE_MARK();  // 1: directory requested
     for (int round = 0;; ++round) {
@@ -432,6 +437,7 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
         __syncthreads();
         const int n = (int)min(s_count, (uint32_t)LIST_CAP);
         if (round != 0) lds_records = false;
+        if (round == 0) n_first = n;
         TRACE_MARK();  // 4: list built
 
         // ---- candidates, 64 at a time: one lane per candidate reads its set-up record once and leaves the tile-local
@@ -499,6 +505,25 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
     }
 
     TRACE_MARK();  // 5: candidates done (one round)
+
+    // Many-channel images (C = 8, 12, 16): the shading pass would gather 3 x C floats per PIXEL from memory (K5: 0.8 GB per
+    // frame through the L2); instead the workgroup copies the colours of its first QCAP candidates' vertices into LDS
+    // once, every thread a few 16-byte pieces, and the pixels read them there.
+    bool quads_in_lds = false;
+    if (LDS_QUADS) {
+        const int Cq = CSPEC ? CSPEC : p.C;
+        quads_in_lds = lds_records && (Cq & 3) == 0 && Cq <= 16 && Cq > 4;
+        if (quads_in_lds) {
+            const int nq = Cq >> 2, ncand = min(min(n_first, QCAP), SHADE_CAP);
+            const float* __restrict__ colsq = p.vertex_colors + (size_t)ib * p.V * Cq;
+            for (int it = tid; it < ncand * 3 * nq; it += RTHREADS) {
+                const int cand = it / (3 * nq), rem = it - cand * 3 * nq, kv = rem / nq, q = rem - kv * nq;
+                const int vid = s_shade[cand].vid[kv];
+                s_colq[(cand * 3 + kv) * 4 + q] = *reinterpret_cast<const float4*>(colsq + (size_t)vid * Cq + 4 * q);
+            }
+            __syncthreads();
+        }
+    }
 
     // ---- shade ----
     // this lane's pixels: background where nothing is visible (requested now, used last)
@@ -583,6 +608,17 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
                 for (int c = 0; c < C; c += 4) *reinterpret_cast<float4*>(out + c) = *reinterpret_cast<const float4*>(bg + c);
             } else {
                 for (int c = 0; c < C; ++c) out[c] = bg[c];
+            }
+        } else if (LDS_QUADS && quads_in_lds && from_lds && cbest[k] < QCAP) {
+            const float4* __restrict__ w = &s_colq[cbest[k] * 12];
+            for (int q = 0; q < (C >> 2); ++q) {
+                const float4 w0 = w[q], w1 = w[4 + q], w2 = w[8 + q];
+                float4 o;
+                o.x = fmaf(b2, w2.x, fmaf(b1, w1.x, b0 * w0.x));
+                o.y = fmaf(b2, w2.y, fmaf(b1, w1.y, b0 * w0.y));
+                o.z = fmaf(b2, w2.z, fmaf(b1, w1.z, b0 * w0.z));
+                o.w = fmaf(b2, w2.w, fmaf(b1, w1.w, b0 * w0.w));
+                *reinterpret_cast<float4*>(out + 4 * q) = o;
             }
         } else {
             const float* __restrict__ c0 = cols + (size_t)vid0 * C;
