@@ -100,6 +100,21 @@ def _require_gpu(*tensors):
     return dev
 
 
+_SIZES = {}   # (B, V, F, H, W, C) -> workspace bytes: a pure function of the sizes, asked once (host-side cost per call)
+_LAYOUTS = {}  # ... -> (offset of grad_vertices, offset of grad_vertex_colors, row strides) of the state's accumulators
+
+
+def _workspace_bytes(lib, B, V, F, H, W, C):
+    key = (B, V, F, H, W, C)
+    n = _SIZES.get(key)
+    if n is None:
+        n = lib.dirt_workspace_bytes(B, V, F, H, W, C)
+        if n == 0:
+            raise ValueError(_lib.last_error())
+        _SIZES[key] = n
+    return n
+
+
 def _dense16(t):
     """A dense tensor whose storage the kernels may access with 16-byte loads: `.contiguous()` returns contiguous
     views unchanged, and a view such as `x[1:]` of a 5x5x3 frame starts at an address that is not a multiple of 16
@@ -128,12 +143,10 @@ def _op_rasterise(background, vertices, vertex_colors, faces, height, width, cha
         flags |= _lib.FLAG_SHARED_FACES
     pixels = torch.empty_like(background)
     with torch.cuda.device(dev):
-        nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, channels)
-        if nbytes == 0:
-            raise ValueError(_lib.last_error())
+        nbytes = _workspace_bytes(lib, B, V, F, height, width, channels)
         if keep_state:
             if state_channels > channels:
-                nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, state_channels)
+                nbytes = _workspace_bytes(lib, B, V, F, height, width, state_channels)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             flags |= _lib.FLAG_KEEP_STATE
         else:
@@ -168,9 +181,7 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
     grad_background = torch.empty_like(pixels)
     debug = torch.empty((B, height, width, 3), dtype=torch.float32, device=dev) if want_debug else None
     with torch.cuda.device(dev):
-        nbytes = lib.dirt_workspace_bytes(B, V, F, height, width, channels)
-        if nbytes == 0:
-            raise ValueError(_lib.last_error())
+        nbytes = _workspace_bytes(lib, B, V, F, height, width, channels)
         if state is not None and state.numel() < nbytes:
             state = None  # sized for fewer channels than this call has: render again
         if state is not None and getattr(state, '_dirt_channels', channels) != channels:
@@ -185,16 +196,22 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
             # the returned tensors are views of it
             ws = state
             flags |= _lib.FLAG_REUSE_STATE
-            gv_p, gvc_p, gv_s, gvc_s = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
-            _lib.check(lib.dirt_state_grad_buffers(ws.data_ptr(), ws.numel(), B, V, F, height, width, channels,
-                                                   ctypes.byref(gv_p), ctypes.byref(gvc_p), ctypes.byref(gv_s), ctypes.byref(gvc_s)))
-            # rows of gv_s / gvc_s floats (C <= 4: both accumulators interleaved in rows of 8): strided views
-            wsf = ws.view(torch.float32) if ws.data_ptr() % 4 == 0 and ws.numel() % 4 == 0 else None
-            if wsf is None:
+            key = (B, V, F, height, width, channels, ws.data_ptr() % 256)
+            layout = _LAYOUTS.get(key)
+            if layout is None:
+                gv_p, gvc_p, gv_s, gvc_s = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+                _lib.check(lib.dirt_state_grad_buffers(ws.data_ptr(), ws.numel(), B, V, F, height, width, channels,
+                                                       ctypes.byref(gv_p), ctypes.byref(gvc_p), ctypes.byref(gv_s), ctypes.byref(gvc_s)))
+                # offsets (in floats) inside the workspace and row strides: they depend on the sizes and on the workspace's
+                # alignment only (the library carves from the next 256-byte boundary)
+                layout = _LAYOUTS[key] = ((gv_p.value - ws.data_ptr()) // 4, (gvc_p.value - ws.data_ptr()) // 4, gv_s.value, gvc_s.value)
+            o1, o2, s1, s2 = layout
+            # rows of s1 / s2 floats (the two accumulators interleaved: one row per vertex): strided views
+            if ws.data_ptr() % 4 != 0 or ws.numel() % 4 != 0:
                 raise RuntimeError('state workspace is not float-aligned')
-            o1, o2 = (gv_p.value - ws.data_ptr()) // 4, (gvc_p.value - ws.data_ptr()) // 4
-            grad_vertices = torch.as_strided(wsf, (B, V, 4), (V * gv_s.value, gv_s.value, 1), o1)
-            grad_vertex_colors = torch.as_strided(wsf, (B, V, channels), (V * gvc_s.value, gvc_s.value, 1), o2)
+            wsf = ws.view(torch.float32)
+            grad_vertices = torch.as_strided(wsf, (B, V, 4), (V * s1, s1, 1), o1)
+            grad_vertex_colors = torch.as_strided(wsf, (B, V, channels), (V * s2, s2, 1), o2)
         else:
             ws = _workspace(dev, nbytes)
             grad_vertices = torch.empty_like(vertices)
