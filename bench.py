@@ -123,6 +123,13 @@ def main():
     def barrier():
         if distributed:
             dist.barrier()
+        # The host polls an event first: torch.cuda.synchronize() on its own returns ~25 us after the last kernel (the
+        # waiting thread has to be woken), which a 20-step timing of a 53 us step would book as 1.2 us per step.  The
+        # synchronisation proper follows and finds nothing left to wait for.
+        done = torch.cuda.Event()
+        done.record()
+        while not done.query():
+            pass
         torch.cuda.synchronize()
 
     # Launch mode of the timed loop: the steps issued eagerly through the Python wrapper, or ONE captured hipGraph of the
