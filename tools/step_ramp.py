@@ -1,9 +1,11 @@
-"""Per-step GPU times of the first steps after a synchronisation (why a 20-step timing costs more per step than a 200-step one)."""
+"""Where a short timing's extra microseconds go: K steps between two synchronisations, host and GPU clocks side by side.
+usage: python tools/step_ramp.py [K]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from dirt_amd import scenes, _lib, rasterise_ops as ops
 _lib.load()
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 F, H, W, C, seed0, r_lo, r_hi = scenes.CONFIGS['K3']
 b = scenes.batch_scene(F, H, W, C, [seed0], r_lo=r_lo, r_hi=r_hi)
 dev = torch.device('cuda:0')
@@ -13,16 +15,21 @@ def step():
     px, state = ops._op_rasterise(bg, v, vc, f, H, W, C, keep_state=True)
     return ops._op_rasterise_grad(v, f, px, g, H, W, C, state=state)
 for _ in range(50): step()
-K = 20
-for rep in range(3):
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+for rep in range(4):
+    e0, e1, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(K):
-        step(); ev[i + 1].record()
+    if rep >= 2: e0.record()
+    step()
     t1 = time.perf_counter()
-    torch.cuda.synchronize()
+    for i in range(K - 1): step()
     t2 = time.perf_counter()
-    d = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(K)]
-    print('wall %.1f us/step (enqueue done at %.0f us, sync returned at %.0f us); GPU event deltas (us):' % ((t2 - t0) / K * 1e6, (t1 - t0) * 1e6, (t2 - t0) * 1e6), ' '.join('%.0f' % x for x in d), ' sum %.0f' % sum(d))
+    if rep >= 2: e1.record()
+    done.record()
+    while not done.query(): pass
+    t3 = time.perf_counter()
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    gpu = e0.elapsed_time(e1) * 1e3 if rep >= 2 else float('nan')
+    print('K=%d: first step issued after %.0f us, all after %.0f us, GPU done (polled) at %.0f us, synchronize returned at %.0f us = %.2f us/step; GPU clock between first and last launch: %.0f us' % (
+        K, (t1 - t0) * 1e6, (t2 - t0) * 1e6, (t3 - t0) * 1e6, (t4 - t0) * 1e6, (t4 - t0) / K * 1e6, gpu))
