@@ -481,17 +481,16 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
             }
             unsigned long long m = __builtin_amdgcn_ballot_w64(mym4 != 0);
             if (m) {
-                int k = __ffsll((long long)m) - 1;
-                TileRec t = s_rec[k];
-                for (;;) {
+                // (no software prefetch of the next candidate's record: holding two records costs 20 registers in a kernel
+                // that sits at the limit for four workgroups per CU, and the other waves of the SIMD cover the LDS latency:
+                // K3 raster 24.3 -> 21.7 us without it)
+                while (m) {
+                    const int k = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    const int kn = m ? __ffsll((long long)m) - 1 : k;
-                    const TileRec tn = s_rec[kn];   // requested before the current candidate is tested
+                    const TileRec t = s_rec[k];
                     const uint32_t m4 = (uint32_t)__builtin_amdgcn_readlane((int)mym4, k);
                     raster_candidate<NB>(t, recs, round == 0 ? cb + k : SHADE_CAP, m4, dxl, dyl, px, py, zbest, fbest, cbest);
                     TRACE_CNT();
-                    if (!m) break;
-                    t = tn; k = kn;
                 }
             }
             TRACE_ACC(2);
