@@ -300,8 +300,7 @@ __device__ __forceinline__ void store_state(const RasterParams& p, size_t pix, f
 //   stage  : 64 candidates at a time, one lane per candidate: the set-up record is read once; its tile-local float32
 //            form (TileRec) goes to LDS, and so does the record itself for the first SHADE_CAP candidates (the shading
 //            pass reads the winners' records from LDS, not from memory);
-//   raster : every wave visits the candidates whose mask touches one of its blocks (next candidate's record
-//            requested while the current one is tested): float32 edge functions classify each sample as certainly
+//   raster : every wave visits the candidates whose mask touches one of its blocks: float32 edge functions classify each sample as certainly
 //            inside / outside, the few in between take the specification's f64 test; then depth from the f64 plane and
 //            a (z24, face) lexicographic min held in registers -- no atomics, independent of list order;
 //   shade  : every lane evaluates the barycentrics of its pixels' winners in f64 (csrc/shaders.cpp:52-57,74) from the
