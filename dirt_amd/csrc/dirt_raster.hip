@@ -263,16 +263,21 @@ __device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec
             const float E1 = fmaf(t.a[1], dx[bx], trow[1]);
             const float E2 = fmaf(t.a[2], dx[bx], trow[2]);
             const float m = fminf(fminf(E0, E1), E2);
-            bool cov = m > t.bound;                                  // certainly inside
-            const bool unsure = !(m > t.bound) & !(m < -t.bound);    // neither certainly inside nor outside (inf / NaN land here)
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(unsure) != 0ull, 0)) {
-                if (unsure) cov = covered_exact(recs + t.face, px[bx], py[by]);
+            // (the predicates as wave-wide lane masks: what combines them is scalar work, and "no lane covered" is a scalar test)
+            unsigned long long cov_m = __builtin_amdgcn_ballot_w64(m > t.bound);                       // certainly inside
+            const unsigned long long unsure_m = __builtin_amdgcn_ballot_w64(!(m < -t.bound)) & ~cov_m;  // neither certainly inside nor outside (inf / NaN land here)
+            if (__builtin_expect(unsure_m != 0ull, 0)) {
+                bool c = false;
+                if (__builtin_amdgcn_inverse_ballot_w64(unsure_m)) c = covered_exact(recs + t.face, px[bx], py[by]);
+                cov_m |= __builtin_amdgcn_ballot_w64(c);
             }
-            if (__builtin_amdgcn_ballot_w64(cov) == 0ull) continue;
+            if (cov_m == 0ull) continue;
             const double q = fma(t.zp[0], px[bx], qrow);
             const uint32_t z24 = (uint32_t)__double_as_longlong(q + 4503599627370496.0);
-            const bool in_range = (unsigned long long)__double_as_longlong(q) <= 0x416FFFFFE0000000ull;   // 0 <= q <= 16777215
-            const bool wins = cov & in_range & ((z24 < zbest[k]) | ((z24 == zbest[k]) & (t.face < fbest[k])));
+            const unsigned long long in_range_m = __builtin_amdgcn_ballot_w64((unsigned long long)__double_as_longlong(q) <= 0x416FFFFFE0000000ull);   // 0 <= q <= 16777215
+            const unsigned long long wins_m = cov_m & in_range_m &
+                (__builtin_amdgcn_ballot_w64(z24 < zbest[k]) | (__builtin_amdgcn_ballot_w64(z24 == zbest[k]) & __builtin_amdgcn_ballot_w64(t.face < fbest[k])));
+            const bool wins = __builtin_amdgcn_inverse_ballot_w64(wins_m);
             zbest[k] = wins ? z24 : zbest[k];
             fbest[k] = wins ? t.face : fbest[k];
             cbest[k] = wins ? ci : cbest[k];
