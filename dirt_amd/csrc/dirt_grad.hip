@@ -489,8 +489,8 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             }
 #pragma unroll
             for (int e = 0; e < NROLES; ++e) {
-#ifdef DIRT_GRAD_NO_ATOMICS
-                if (role_valid[e] && total[e] == 1.2345e-30f && vsel[e] == -12345)   // (experiment: never true; keeps the operands alive)
+#ifdef DIRT_GRAD_NO_ATOMICS   // measurement builds only (what the atomics cost: profiles/README.md); never defined for the product library
+                if (role_valid[e] && total[e] == 1.2345e-30f && vsel[e] == -12345)   // (never true; keeps the operands alive)
 #else
                 if (role_valid[e] && total[e] != 0.f)
 #endif
