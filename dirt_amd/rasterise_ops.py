@@ -333,6 +333,26 @@ def _rasterise_grad_multichannel(vertices, faces, pixels, d_loss_by_pixels, sing
     return {'grad_vertices': gv, 'grad_vertex_colors': gvc, 'grad_background': gb}
 
 
+def _unlisted_leaves(output, listed, limit=20000):
+    """Leaf tensors that `output` depends on (requires_grad) and that are not in `listed`: parameters a shader closes over
+    without naming them in `shader_parameters`.  TensorFlow's custom_gradient hands those to the gradient function as
+    `variables` (dirt/rasterise_ops.py:239-246); a torch.autograd.Function cannot, so they would silently get no gradient."""
+    if not isinstance(output, torch.Tensor) or output.grad_fn is None:
+        return []
+    known = {id(t) for t in listed if isinstance(t, torch.Tensor)}
+    found, seen, stack = [], set(), [output.grad_fn]   # (the nodes themselves are kept: ids of dead wrappers get reused)
+    while stack and len(seen) < limit:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        var = getattr(fn, 'variable', None)   # AccumulateGrad: a leaf
+        if var is not None and id(var) not in known and all(var is not f for f in found):
+            found.append(var)
+        stack.extend(nf for nf, _ in fn.next_functions)
+    return found
+
+
 class _RasteriseDeferred(torch.autograd.Function):
     """`_rasterise_deferred_internal._impl` (dirt/rasterise_ops.py:189-248) as a custom autograd node."""
 
@@ -357,6 +377,13 @@ class _RasteriseDeferred(torch.autograd.Function):
             extra_in = [t.detach().requires_grad_(t.is_floating_point()) if isinstance(t, torch.Tensor) else t
                         for t in shader_additional_inputs]
             pixels = shader_fn(gbuffer_in, *extra_in)
+        stray = _unlisted_leaves(pixels, [gbuffer_in] + list(extra_in) + list(shader_params))
+        if stray:
+            import warnings
+            warnings.warn('rasterise_deferred: shader_fn uses %d tensor(s) that require grad but are neither '
+                          'shader_additional_inputs nor shader_parameters (shapes %s); they will receive no gradient. '
+                          'Pass them as shader_parameters=[...] (the counterpart of the `variables` TensorFlow hands to '
+                          'a custom_gradient).' % (len(stray), [tuple(t.shape) for t in stray[:4]]), stacklevel=3)
         ctx.single_or_batch = single_or_batch
         ctx.n_extra = n_extra
         ctx.n_params = len(shader_params)

@@ -223,3 +223,19 @@ def test_texture_lookup_matches_a_restatement():
     uu = torch.from_numpy(uv).requires_grad_(True)
     tex.sample_texture(tt, tex.uvs_to_pixel_indices(uu, (7, 5))).sum().backward()
     assert float(tt.grad.sum()) == pytest.approx(uv.shape[0] * uv.shape[1] * 3) and torch.isfinite(uu.grad).all()
+
+
+def test_unlisted_shader_parameters_are_detected():
+    """A shader that closes over a parameter it does not list gets a warning, not a silently missing gradient (the
+    reference's TensorFlow custom_gradient receives such `variables` automatically, dirt/rasterise_ops.py:239-246)."""
+    import torch
+    from dirt_amd.rasterise_ops import _unlisted_leaves
+    g = torch.zeros(4, 4, 3, requires_grad=True)
+    listed_w = torch.ones(3, requires_grad=True)
+    stray_w = torch.full((3,), 2.0, requires_grad=True)
+    constant = torch.ones(3)
+    out = (g * listed_w).sum(-1) + (g * stray_w * constant).sum(-1)
+    found = _unlisted_leaves(out, [g, listed_w])
+    assert len(found) == 1 and found[0] is stray_w
+    assert _unlisted_leaves(out, [g, listed_w, stray_w]) == []
+    assert _unlisted_leaves(torch.ones(3), [g]) == []          # no graph at all
