@@ -72,6 +72,11 @@
 #endif
 
 #define DIRT_ORACLE_FLAG_Q1_INTENDED 1u /* L1 over the real channels of a 1-channel group */
+/* Accumulate exactly as ONE CUDA thread walking the reference's loops would: float32 adds, pixels in the
+   order of CUDA_AXIS_KERNEL_LOOP(buffer_x){CUDA_AXIS_KERNEL_LOOP(buffer_y)} (csrc/rasterise_grad_egl.cu:
+   106-107), one accumulator per channel group, groups then added in float32 (dirt/rasterise_ops.py:163).
+   With it the oracle must equal oracle/_ref (the reference's kernel compiled for the host) BIT FOR BIT. */
+#define DIRT_ORACLE_FLAG_F32_SEQUENTIAL 2u
 
 typedef struct {
     double a[3], b[3], c[3];
@@ -323,6 +328,20 @@ static inline void atomic_add_d(double *p, double v)
     *p += v;
 }
 
+/* One accumulation: `acc` is the sum (double; rounded to float32 after every add in the sequential
+   mode -- a double add of two floats rounded to float IS the float add, 53 >= 2*24+2), `mass` (may be
+   NULL) the L1 mass of the terms, the scale the per-element tolerance of the parity tests refers to. */
+static inline void accumulate(double *acc, double *mass, size_t idx, float term, float term_mass, int seq)
+{
+    if (seq) {
+        acc[idx] = (double)(float)(acc[idx] + (double)term);
+        if (mass) mass[idx] += (double)term_mass;
+    } else {
+        atomic_add_d(&acc[idx], (double)term);
+        if (mass) atomic_add_d(&mass[idx], (double)term_mass);
+    }
+}
+
 /*
  * assemble_grads for one scene and ONE channel group (csrc/rasterise_grad_egl.cu:93-236).
  * `pix` / `gpix` are the group's contiguous [B,H,W,G] slices (what TF hands the op after
@@ -331,6 +350,7 @@ static inline void atomic_add_d(double *p, double v)
  * Variable names follow the CUDA source.
  */
 static void assemble_grads_group(double *grad_vertices /*[V,4]*/, double *grad_vertex_colors /*[V,C] */,
+                                 double *mass_vertices /*[V,4] or NULL*/, double *mass_vertex_colors /*[V,C] or NULL*/,
                                  float *grad_background /*[H,W,C] of this scene*/, float *debug_thingy /*[H,W,3] or NULL*/,
                                  const float *bary_w, const float *index_f, const float *pix, const float *gpix,
                                  const float *vertices /*[V,4] of this scene*/, int iib, int B, int H, int W, int G,
@@ -338,9 +358,14 @@ static void assemble_grads_group(double *grad_vertices /*[V,4]*/, double *grad_v
 {
     const int frame_height = H, frame_width = W, channels = G;
     const size_t total = (size_t)B * H * W * G;
-#pragma omp parallel for schedule(static)
-    for (int buffer_y = 0; buffer_y < H; ++buffer_y) {
-        for (int buffer_x = 0; buffer_x < W; ++buffer_x) {
+    const int seq = (flags & DIRT_ORACLE_FLAG_F32_SEQUENTIAL) != 0;
+    const long n_pixels = (long)H * W;
+#pragma omp parallel for schedule(static) if (!seq)
+    for (long n = 0; n < n_pixels; ++n) {
+        {
+            /* parallel: row-major; sequential: buffer_x outer, buffer_y inner, as one thread of the reference walks */
+            const int buffer_y = seq ? (int)(n % H) : (int)(n / W);
+            const int buffer_x = seq ? (int)(n / H) : (int)(n % W);
             const int x_in_frame = buffer_x;
             const int y_in_frame = frame_height - 1 - buffer_y; /* :111 vertical flip */
 
@@ -392,7 +417,8 @@ static void assemble_grads_group(double *grad_vertices /*[V,4]*/, double *grad_v
                     int vertex_index = (int)index_f3[k];
                     for (int channel = 0; channel < channels; ++channel) {
                         float color_grad = g_here[channel] * barycentric[k];
-                        atomic_add_d(&grad_vertex_colors[(size_t)vertex_index * C + c_begin + channel], (double)color_grad);
+                        accumulate(grad_vertex_colors, mass_vertex_colors, (size_t)vertex_index * C + c_begin + channel,
+                                   color_grad, fabsf(color_grad), seq);
                     }
                 }
             } else {
@@ -469,9 +495,9 @@ static void assemble_grads_group(double *grad_vertices /*[V,4]*/, double *grad_v
                     float gy = dLy_b * d_yview_by_yclip;
                     float gw1 = dLx_b * d_xview_by_wclip, gw2 = dLy_b * d_yview_by_wclip;
                     float gw = gw1 + gw2;
-                    atomic_add_d(&grad_vertices[(size_t)vertex_index * 4 + 0], (double)gx);
-                    atomic_add_d(&grad_vertices[(size_t)vertex_index * 4 + 1], (double)gy);
-                    atomic_add_d(&grad_vertices[(size_t)vertex_index * 4 + 3], (double)gw);
+                    accumulate(grad_vertices, mass_vertices, (size_t)vertex_index * 4 + 0, gx, fabsf(gx), seq);
+                    accumulate(grad_vertices, mass_vertices, (size_t)vertex_index * 4 + 1, gy, fabsf(gy), seq);
+                    accumulate(grad_vertices, mass_vertices, (size_t)vertex_index * 4 + 3, gw, fabsf(gw1) + fabsf(gw2), seq);
                 }
             }
         }
@@ -484,18 +510,24 @@ static void assemble_grads_group(double *grad_vertices /*[V,4]*/, double *grad_v
  * remain, then singles; grad_vertices summed over groups, the other two concatenated.
  * debug_thingy (optional, [B,H,W,3]) is that of the FIRST group.
  */
-int dirt_oracle_backward(const float *vertices, const int32_t *faces, const float *pixels, const float *grad_pixels,
-                         float *grad_background, float *grad_vertices, float *grad_vertex_colors, float *debug_thingy,
-                         int B, int V, int F, int H, int W, int C, unsigned flags)
+int dirt_oracle_backward_ex(const float *vertices, const int32_t *faces, const float *pixels, const float *grad_pixels,
+                            float *grad_background, float *grad_vertices, float *grad_vertex_colors, float *debug_thingy,
+                            float *mass_vertices /*[B,V,4] or NULL*/, float *mass_vertex_colors /*[B,V,C] or NULL*/,
+                            int B, int V, int F, int H, int W, int C, unsigned flags)
 {
     if (!check_dims(B, V, F, H, W, C)) return -1;
     if (V > (1 << 24)) return -2; /* csrc/rasterise_grad_egl.cpp:399-405 */
+    const int seq = (flags & DIRT_ORACLE_FLAG_F32_SEQUENTIAL) != 0;
     size_t P = (size_t)H * W;
+    size_t nv = (size_t)B * V * 4, nvc = (size_t)B * V * C;
     /* launch_grad_assembly zeroes every output first: csrc/rasterise_grad_egl.cu:244-250 */
     memset(grad_background, 0, sizeof(float) * (size_t)B * P * C);
     if (debug_thingy) memset(debug_thingy, 0, sizeof(float) * (size_t)B * P * 3);
-    double *gv = (double *)calloc((size_t)B * V * 4 + 1, sizeof(double));
-    double *gvc = (double *)calloc((size_t)B * V * C + 1, sizeof(double));
+    double *gv = (double *)calloc(nv + 1, sizeof(double));
+    double *gv_group = seq ? (double *)calloc(nv + 1, sizeof(double)) : gv; /* one op call's grad_vertices */
+    double *gvc = (double *)calloc(nvc + 1, sizeof(double));
+    double *mv = mass_vertices ? (double *)calloc(nv + 1, sizeof(double)) : NULL;
+    double *mvc = mass_vertex_colors ? (double *)calloc(nvc + 1, sizeof(double)) : NULL;
     float *bary_w = (float *)malloc(sizeof(float) * P * 4);
     float *index_f = (float *)malloc(sizeof(float) * P * 3);
     float *pix_g = (float *)malloc(sizeof(float) * (size_t)B * P * 3);
@@ -509,21 +541,37 @@ int dirt_oracle_backward(const float *vertices, const int32_t *faces, const floa
                 pix_g[n * G + ch] = pixels[n * C + c_begin + ch];
                 gpix_g[n * G + ch] = grad_pixels[n * C + c_begin + ch];
             }
+        if (seq) memset(gv_group, 0, sizeof(double) * nv);
         for (int ib = 0; ib < B; ++ib) {
             const float *verts = vertices + (size_t)ib * V * 4;
             OFace *of = setup_scene(verts, V, faces + (size_t)ib * F * 3, F, H, W);
             scene_surfaces(of, F, H, W, bary_w, index_f);
-            assemble_grads_group(gv + (size_t)ib * V * 4, gvc + (size_t)ib * V * C, grad_background + (size_t)ib * P * C,
+            assemble_grads_group(gv_group + (size_t)ib * V * 4, gvc + (size_t)ib * V * C,
+                                 mv ? mv + (size_t)ib * V * 4 : NULL, mvc ? mvc + (size_t)ib * V * C : NULL,
+                                 grad_background + (size_t)ib * P * C,
                                  (debug_thingy && c_begin == 0) ? debug_thingy + (size_t)ib * P * 3 : NULL, bary_w, index_f,
                                  pix_g, gpix_g, verts, ib, B, H, W, G, C, c_begin, flags);
             free(of);
         }
+        if (seq) /* `sum([result.grad_vertices ...])` in float32, dirt/rasterise_ops.py:163 */
+            for (size_t n = 0; n < nv; ++n) gv[n] = (double)(float)(gv[n] + gv_group[n]);
         c_begin += G;
     }
-    for (size_t n = 0; n < (size_t)B * V * 4; ++n) grad_vertices[n] = (float)gv[n];
-    for (size_t n = 0; n < (size_t)B * V * C; ++n) grad_vertex_colors[n] = (float)gvc[n];
-    free(gv); free(gvc); free(bary_w); free(index_f); free(pix_g); free(gpix_g);
+    for (size_t n = 0; n < nv; ++n) grad_vertices[n] = (float)gv[n];
+    for (size_t n = 0; n < nvc; ++n) grad_vertex_colors[n] = (float)gvc[n];
+    if (mv) for (size_t n = 0; n < nv; ++n) mass_vertices[n] = (float)mv[n];
+    if (mvc) for (size_t n = 0; n < nvc; ++n) mass_vertex_colors[n] = (float)mvc[n];
+    if (seq) free(gv_group);
+    free(gv); free(gvc); free(mv); free(mvc); free(bary_w); free(index_f); free(pix_g); free(gpix_g);
     return 0;
+}
+
+int dirt_oracle_backward(const float *vertices, const int32_t *faces, const float *pixels, const float *grad_pixels,
+                         float *grad_background, float *grad_vertices, float *grad_vertex_colors, float *debug_thingy,
+                         int B, int V, int F, int H, int W, int C, unsigned flags)
+{
+    return dirt_oracle_backward_ex(vertices, faces, pixels, grad_pixels, grad_background, grad_vertices, grad_vertex_colors,
+                                   debug_thingy, NULL, NULL, B, V, F, H, W, C, flags);
 }
 
 /*

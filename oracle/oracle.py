@@ -14,6 +14,7 @@ _SO = os.path.join(_HERE, 'libdirt_oracle.so')
 _lib = None
 
 FLAG_Q1_INTENDED = 1
+FLAG_F32_SEQUENTIAL = 2  # float32 adds in the order one thread of the reference's kernel makes them: equals oracle/_ref bit for bit
 
 
 def build(force=False):
@@ -41,6 +42,8 @@ def _load():
     lib.dirt_oracle_forward.restype = i
     lib.dirt_oracle_backward.argtypes = [fp, ip, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, ctypes.c_uint]
     lib.dirt_oracle_backward.restype = i
+    lib.dirt_oracle_backward_ex.argtypes = [fp, ip, fp, fp, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, ctypes.c_uint]
+    lib.dirt_oracle_backward_ex.restype = i
     lib.dirt_oracle_visibility.argtypes = [fp, ip, ip, fp, fp, i, i, i, i]
     lib.dirt_oracle_visibility.restype = i
     lib.dirt_oracle_num_threads.restype = i
@@ -87,8 +90,13 @@ def forward(background, vertices, vertex_colors, faces):
     return pixels
 
 
-def backward(vertices, faces, pixels, grad_pixels, flags=0, want_debug=False):
-    """-> dict(grad_background [B,H,W,C], grad_vertices [B,V,4], grad_vertex_colors [B,V,C][, debug_thingy [B,H,W,3]])."""
+def backward(vertices, faces, pixels, grad_pixels, flags=0, want_debug=False, want_mass=False):
+    """-> dict(grad_background [B,H,W,C], grad_vertices [B,V,4], grad_vertex_colors [B,V,C][, debug_thingy [B,H,W,3]]
+    [, mass_vertices [B,V,4], mass_vertex_colors [B,V,C]]).
+
+    `mass_*` is, per output element, the sum of |term| over everything the reference's atomics add into
+    it (csrc/rasterise_grad_egl.cu:140,228-230; for `.w` the two products of :230 count separately): the
+    scale of the per-element tolerance |gpu - oracle| <= 1e-4 * mass of the parity tests."""
     lib = _load()
     vertices, faces, pixels, grad_pixels = _f(vertices), _i(faces), _f(pixels), _f(grad_pixels)
     B, H, W, C = pixels.shape
@@ -98,13 +106,19 @@ def backward(vertices, faces, pixels, grad_pixels, flags=0, want_debug=False):
     gv = np.empty((B, V, 4), np.float32)
     gvc = np.empty((B, V, C), np.float32)
     dbg = np.empty((B, H, W, 3), np.float32) if want_debug else None
-    rc = lib.dirt_oracle_backward(_fp(vertices), _ip(faces), _fp(pixels), _fp(grad_pixels), _fp(gb), _fp(gv), _fp(gvc),
-                                  _fp(dbg) if want_debug else None, B, V, F, H, W, C, flags)
+    mv = np.empty((B, V, 4), np.float32) if want_mass else None
+    mvc = np.empty((B, V, C), np.float32) if want_mass else None
+    rc = lib.dirt_oracle_backward_ex(_fp(vertices), _ip(faces), _fp(pixels), _fp(grad_pixels), _fp(gb), _fp(gv), _fp(gvc),
+                                     _fp(dbg) if want_debug else None, _fp(mv) if want_mass else None,
+                                     _fp(mvc) if want_mass else None, B, V, F, H, W, C, flags)
     if rc != 0:
         raise ValueError('dirt_oracle_backward failed: %d' % rc)
     out = {'grad_background': gb, 'grad_vertices': gv, 'grad_vertex_colors': gvc}
     if want_debug:
         out['debug_thingy'] = dbg
+    if want_mass:
+        out['mass_vertices'] = mv
+        out['mass_vertex_colors'] = mvc
     return out
 
 

@@ -1,0 +1,153 @@
+"""ctypes/numpy front-end of oracle/_ref/libdirt_ref.so -- the reference's OWN `assemble_grads`
+(csrc/rasterise_grad_egl.cu:93-236) and `launch_grad_assembly` (:238-278) compiled for the host
+(oracle/make_ref.py, oracle/ref_shim/).  TEST INFRASTRUCTURE: pins oracle/dirt_oracle.c's backward
+restatement to the reference's kernel source.
+
+What is the reference's and what is not:
+  * every gradient operation, the zeroing of the outputs, the atlas indexing (`iib`, the vertical
+    flip), quirk Q1's aliasing reads: the reference's code, executed here;
+  * the two surfaces the kernel reads are rendered by NVIDIA's OpenGL driver in the reference
+    (csrc/rasterise_grad_egl.cpp:432-456, csrc/shaders.cpp:45-79); here they are filled from the
+    oracle's specification-pinned visibility (`oracle.visibility`), over the reference's clear values
+    (csrc/rasterise_grad_egl.cpp:442-445), in the reference's atlas layout (:408-428);
+  * the channel-group loop is dirt/rasterise_ops.py:132-177 restated over numpy (TensorFlow is absent).
+"""
+import ctypes
+import math
+import numpy as np
+
+from . import make_ref
+from . import oracle as _oracle
+
+_lib = None
+
+
+def available():
+    return make_ref.build() is not None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        so = make_ref.build()
+        if so is None:
+            raise RuntimeError('oracle/_ref is not built and /root/reference is not present')
+        lib = ctypes.CDLL(so)
+        fp = ctypes.POINTER(ctypes.c_float)
+        i = ctypes.c_int
+        lib.dirt_ref_rasterise_grad.argtypes = [fp] * 9 + [i] * 7
+        lib.dirt_ref_rasterise_grad.restype = i
+        lib.dirt_ref_upload_vertices.argtypes = [fp, ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p, i, i, i]
+        lib.dirt_ref_upload_vertices.restype = i
+        _lib = lib
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def atlas_shape(batch_size, height, width):
+    """Framebuffer size RasteriseGradOpGpu::Compute chooses for a batch, csrc/rasterise_grad_egl.cpp:408-414."""
+    horizontal_count = int(math.sqrt(np.float32(batch_size)) + np.float32(.1))
+    vertical_count = batch_size // horizontal_count + (0 if batch_size % horizontal_count == 0 else 1)
+    return height * vertical_count, width * horizontal_count
+
+
+def surfaces(vertices, faces, height, width):
+    """The two RGBA32F colour attachments after the backward render of a batch:
+    (barycentrics_and_depth, indices), each [buffer_height, buffer_width, 4], GL orientation."""
+    B = vertices.shape[0]
+    bh, bw = atlas_shape(B, height, width)
+    bary_w = np.empty((bh, bw, 4), np.float32)
+    bary_w[..., :3] = -1.
+    bary_w[..., 3] = np.inf  # clear values, csrc/rasterise_grad_egl.cpp:442-445
+    index = np.full((bh, bw, 4), -1., np.float32)
+    frames_per_row = bw // width
+    for ib in range(B):
+        fid, bary, cw = _oracle.visibility(vertices[ib], faces[ib], height, width)
+        frame_x = (ib % frames_per_row) * width     # glViewport, csrc/rasterise_grad_egl.cpp:434-437
+        frame_y = (ib // frames_per_row) * height
+        covered = fid >= 0
+        tri = np.asarray(faces[ib], np.int64)[np.where(covered, fid, 0)].astype(np.float32)  # flat ivec3 -> float, shaders.cpp:53,76
+        tile_b = np.concatenate([bary, cw[..., None]], -1)
+        tile_i = np.where(covered[..., None], np.concatenate([tri, np.full(fid.shape + (1,), -1., np.float32)], -1), np.float32(-1.))
+        bary_w[frame_y:frame_y + height, frame_x:frame_x + width] = tile_b[::-1]  # tensor rows are top-first
+        index[frame_y:frame_y + height, frame_x:frame_x + width] = tile_i[::-1]
+    return bary_w, index
+
+
+def rasterise_grad_op(vertices, faces, pixels, grad_pixels, surf=None):
+    """One `RasteriseGrad` op call, channels in {1, 3} -> dict like the op's namedtuple (dirt/rasterise_ops.py:113-128)."""
+    lib = _load()
+    vertices = np.ascontiguousarray(vertices, np.float32)
+    faces = np.ascontiguousarray(faces, np.int32)
+    B, H, W, C = pixels.shape
+    V = vertices.shape[1]
+    assert C in (1, 3) and grad_pixels.shape == pixels.shape and vertices.shape == (B, V, 4)
+    if V > (1 << 24):
+        raise ValueError('RasteriseGrad supports a maximum of %d vertices' % (1 << 24))  # csrc/rasterise_grad_egl.cpp:399-405
+
+    def padded(a):
+        # Quirk Q1: for C == 1 the kernel reads two floats past each pixel, so past the end of the
+        # tensor for the last two pixels (undefined in the reference).  The oracle defines those
+        # reads as the last element; pad accordingly.
+        flat = np.ascontiguousarray(a, np.float32).reshape(-1)
+        return np.concatenate([flat, np.repeat(flat[-1:], 2)])
+
+    pix, gpix = padded(pixels), padded(grad_pixels)
+    bary_w, index = surf if surf is not None else surfaces(vertices, faces, H, W)
+    bh, bw = bary_w.shape[:2]
+    out = {'grad_background': np.full((B, H, W, C), np.nan, np.float32),
+           'grad_vertices': np.full((B, V, 4), np.nan, np.float32),
+           'grad_vertex_colors': np.full((B, V, C), np.nan, np.float32),
+           'debug_thingy': np.full((B, H, W, 3), np.nan, np.float32)}
+    rc = lib.dirt_ref_rasterise_grad(_fp(vertices), _fp(pix), _fp(gpix), _fp(bary_w), _fp(index),
+                                     _fp(out['grad_background']), _fp(out['grad_vertices']), _fp(out['grad_vertex_colors']),
+                                     _fp(out['debug_thingy']), B, V, H, W, C, bw, bh)
+    if rc != 0:
+        raise ValueError('dirt_ref_rasterise_grad failed: %d' % rc)
+    return out
+
+
+def backward(vertices, faces, pixels, grad_pixels):
+    """`_rasterise_grad_multichannel(..., 'batch')`, dirt/rasterise_ops.py:132-177: groups of three
+    channels while three remain, then singles; grad_vertices summed, the others concatenated.
+    debug_thingy is the first group's (what oracle.backward exports)."""
+    pixels = np.asarray(pixels, np.float32)
+    grad_pixels = np.asarray(grad_pixels, np.float32)
+    vertices = np.ascontiguousarray(vertices, np.float32)
+    faces = np.ascontiguousarray(faces, np.int32)
+    channels = pixels.shape[3]
+    surf = surfaces(vertices, faces, pixels.shape[1], pixels.shape[2])
+    results = []
+    begin_channel = 0
+    while begin_channel < channels:
+        end_channel = begin_channel + 3 if begin_channel + 3 <= channels else begin_channel + 1
+        results.append(rasterise_grad_op(vertices, faces, pixels[..., begin_channel:end_channel],
+                                         grad_pixels[..., begin_channel:end_channel], surf))
+        begin_channel = end_channel
+    grad_vertices = results[0]['grad_vertices']
+    for result in results[1:]:
+        grad_vertices = grad_vertices + result['grad_vertices']  # fp32 sum over groups, as tf's `sum`
+    return {'grad_vertices': grad_vertices,
+            'grad_vertex_colors': np.concatenate([r['grad_vertex_colors'] for r in results], -1),
+            'grad_background': np.concatenate([r['grad_background'] for r in results], -1),
+            'debug_thingy': results[0]['debug_thingy']}
+
+
+def upload_vertices(vertices, faces):
+    """The expanded vertex buffer of the backward render (csrc/rasterise_grad_egl.cu:11-33):
+    -> structured array [B, 3F] of (position[4], barycentric[2], indices[3])."""
+    lib = _load()
+    vertices = np.ascontiguousarray(vertices, np.float32)
+    faces = np.ascontiguousarray(faces, np.int32)
+    B, V = vertices.shape[:2]
+    F = faces.shape[1]
+    dt = np.dtype([('position', np.float32, 4), ('barycentric', np.float32, 2), ('indices', np.int32, 3)])
+    out = np.zeros((B, 3 * F), dt)
+    rc = lib.dirt_ref_upload_vertices(_fp(vertices), faces.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                      out.ctypes.data_as(ctypes.c_void_p), B, V, F)
+    if rc != 0:
+        raise ValueError('dirt_ref_upload_vertices failed: %d' % rc)
+    return out

@@ -12,12 +12,26 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+class _OracleWithMass:
+    """The oracle package with `backward` returning the per-element L1 masses by default (tests/parity.py)."""
+
+    def __init__(self, module):
+        self._module = module
+
+    def __getattr__(self, name):
+        return getattr(self._module, name)
+
+    def backward(self, *args, **kw):
+        kw.setdefault('want_mass', True)
+        return self._module.backward(*args, **kw)
+
+
 @pytest.fixture(scope='session')
 def oracle():
     """The CPU oracle (test infrastructure); built on demand with gcc."""
     import oracle as _oracle
     _oracle.build()
-    return _oracle
+    return _OracleWithMass(_oracle)
 
 
 @pytest.fixture(scope='session')

@@ -1,12 +1,15 @@
 """Writes the golden fixtures tests/golden/*.npz.
 
-The reference cannot be imported or run in this container (TensorFlow, CUDA and NVIDIA EGL are absent;
-its kernels are DEVICE_GPU only) and it ships no stored expected arrays, so these vectors come from the
-CPU oracle, which is itself pinned by tests/test_oracle.py (square_test known answer, exact-arithmetic
-coverage, analytic interpolation, numpy restatement of assemble_grads).  They let the GPU box compare
-the HIP path with committed numbers, and they detect drift of the oracle.
+The reference's ops cannot be imported or run in this container (TensorFlow, CUDA and NVIDIA EGL are
+absent; its kernels are DEVICE_GPU only) and it ships no stored expected arrays.  Two kinds of vectors:
+  * <case>.npz: the CPU oracle's forward, visibility and backward (with the per-element L1 mass the
+    parity tolerance refers to), pinned by tests/test_oracle.py;
+  * ref_grads.npz (`--ref`, needs /root/reference): for the same cases, the output of the REFERENCE'S OWN
+    `assemble_grads` / `launch_grad_assembly` compiled for the host (oracle/make_ref.py), fed the oracle's
+    visibility surfaces.  tests/test_oracle_ref.py requires the oracle to reproduce these bit for bit
+    wherever the tests run (the reference itself does not travel to the GPU box).
 
-Run from the repository root:  python -m tests.golden.make_golden
+Run from the repository root:  python -m tests.golden.make_golden [--ref]
 """
 import os
 import sys
@@ -70,7 +73,7 @@ def main():
     for name, case in CASES.items():
         s = make_inputs(case)
         px = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
-        out = oracle.backward(s['vertices'], s['faces'], px, s['grad_pixels'])
+        out = oracle.backward(s['vertices'], s['faces'], px, s['grad_pixels'], want_mass=True)
         fid = np.stack([oracle.visibility(s['vertices'][i], s['faces'][i], px.shape[1], px.shape[2])[0]
                         for i in range(px.shape[0])])
         path = os.path.join(HERE, name + '.npz')
@@ -78,5 +81,20 @@ def main():
         print('%-18s %s  %d bytes' % (name, px.shape, os.path.getsize(path)))
 
 
+def main_ref():
+    import oracle
+    from oracle import ref
+    out = {}
+    for name, case in CASES.items():
+        s = make_inputs(case)
+        px = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
+        r = ref.backward(s['vertices'], s['faces'], px, s['grad_pixels'])
+        for k, v in r.items():
+            out[name + '/' + k] = v
+    path = os.path.join(HERE, 'ref_grads.npz')
+    np.savez_compressed(path, **out)
+    print('ref_grads.npz: %d arrays, %d bytes' % (len(out), os.path.getsize(path)))
+
+
 if __name__ == '__main__':
-    main()
+    main_ref() if '--ref' in sys.argv else main()

@@ -16,6 +16,7 @@ import torch
 
 from dirt_amd import scenes
 from dirt_amd import rasterise_ops as ops
+from tests import parity
 
 pytestmark = pytest.mark.gpu
 
@@ -112,12 +113,9 @@ def test_deferred_matches_manual_composition(gpu, oracle):
     shaded.backward(d)
     want_v = oracle.backward(s['vertices'][None], s['faces'][None], shaded.detach().cpu().numpy()[None], d.cpu().numpy()[None])
     want_a = oracle.backward(s['vertices'][None], s['faces'][None], gbuf, gt.grad.cpu().numpy()[None])
-    def close(got, want, what):
-        scale = max(1.0, float(np.abs(want).max()))
-        assert float(np.abs(got.cpu().numpy() - want).max()) <= 1e-4 * scale, what
-    close(v.grad, want_v['grad_vertices'][0], 'vertices')
-    close(attrs.grad, want_a['grad_vertex_colors'][0], 'attributes')
-    close(bg.grad, want_a['grad_background'][0], 'background')
+    parity.grad_close(v.grad, want_v, 'grad_vertices', 'vertices', 0)
+    parity.grad_close(attrs.grad, want_a, 'grad_vertex_colors', 'attributes', 0)
+    assert np.array_equal(bg.grad.cpu().numpy(), want_a['grad_background'][0]), 'background'
     assert torch.allclose(light.grad, l2.grad, rtol=1e-4, atol=1e-4)
 
 
@@ -149,12 +147,9 @@ def test_batch_deferred_shares_one_visibility_pass(gpu, oracle, shaded_channels)
     want_v = oracle.backward(batch['vertices'], batch['faces'], shaded.detach().cpu().numpy(), d.cpu().numpy())
     want_a = oracle.backward(batch['vertices'], batch['faces'], gbuf, gt.grad.cpu().numpy())
 
-    def close(got, want, what):
-        scale = max(1.0, float(np.abs(want).max()))
-        assert float(np.abs(got.cpu().numpy() - want).max()) <= 1e-4 * scale, what
-    close(v.grad, want_v['grad_vertices'], 'vertices')
-    close(attrs.grad, want_a['grad_vertex_colors'], 'attributes')
-    close(bg.grad, want_a['grad_background'], 'background')
+    parity.grad_close(v.grad, want_v, 'grad_vertices', 'vertices')
+    parity.grad_close(attrs.grad, want_a, 'grad_vertex_colors', 'attributes')
+    assert np.array_equal(bg.grad.cpu().numpy(), want_a['grad_background']), 'background'
 
 
 def test_step_is_capturable_in_a_hip_graph(gpu):
@@ -235,7 +230,7 @@ def _deferred_reference(oracle, clip, faces, attributes, n_channels, H, W, shade
     shaded.backward(d)
     want_v = oracle.backward(clip_np[None], faces_np[None], shaded.detach().cpu().numpy()[None], d.cpu().numpy()[None])
     want_a = oracle.backward(clip_np[None], faces_np[None], gbuf, gt.grad.cpu().numpy()[None])
-    return shaded.detach(), want_v['grad_vertices'][0], want_a['grad_vertex_colors'][0]
+    return shaded.detach(), want_v, want_a
 
 
 def _close(got, want, what, tol=1e-4):
@@ -276,8 +271,8 @@ def test_textured_sample_end_to_end(gpu, oracle):
 
     shaded, want_v, want_a = _deferred_reference(oracle, clip, faces, attributes, 6, H, W, shade, d)
     assert torch.allclose(px, shaded, atol=1e-6)
-    _close(clip.grad, want_v, 'clip-space vertices')
-    _close(attributes.grad, want_a, 'vertex attributes')
+    parity.grad_close(clip.grad, want_v, 'grad_vertices', 'clip-space vertices', 0)
+    parity.grad_close(attributes.grad, want_a, 'grad_vertex_colors', 'vertex attributes', 0)
     _close(texture.grad, tex2.grad, 'texture')
     _close(light.grad, light2.grad, 'light direction', tol=1e-5)
 
@@ -305,7 +300,7 @@ def test_deferred_sample_end_to_end(gpu, oracle):
     light2 = light.detach().clone().requires_grad_(True)
     shaded, want_v, want_a = _deferred_reference(oracle, clip, faces, attributes, 10, H, W, lambda g: ex.shader_fn(g, view2, light2), d)
     assert torch.allclose(px, shaded, atol=1e-6)
-    _close(clip.grad, want_v, 'clip-space vertices')
-    _close(attributes.grad, want_a, 'vertex attributes')
+    parity.grad_close(clip.grad, want_v, 'grad_vertices', 'clip-space vertices', 0)
+    parity.grad_close(attributes.grad, want_a, 'grad_vertex_colors', 'vertex attributes', 0)
     _close(view_in.grad, view2.grad, 'view matrix', tol=1e-5)
     _close(light_in.grad, light2.grad, 'light direction', tol=1e-5)
