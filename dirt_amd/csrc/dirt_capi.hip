@@ -92,7 +92,7 @@ struct Workspace {
 };
 
 // Layout: [FaceRec x B*F | FaceBox x B*F | chunk x bin directory | per-chunk BinEntry segments (5 per face) |
-//          float2 per-pixel state {clip_w, face} x B*H*W | float2 {b0, b1} x B*H*W | gradient accumulators:
+//          float2 per-pixel state {clip_w, face} x B*H*W | float2 barycentric pair (encode_bary) x B*H*W | gradient accumulators:
 //          float x B*V*(4 + C rounded up to 4): a vertex's position and colour gradients in one row]
 Workspace carve(int B, int V, int F, int H, int W, int C)
 {

@@ -170,6 +170,32 @@ __device__ inline void bary_eval(const double F[3], uint32_t flags, double inv_d
     clip_w = r;
 }
 
+// The backward pass's per-pixel barycentrics travel as TWO floats (state plane B).  Which two: always the two that are
+// not the largest -- the third is re-derived as (1 - p) - q, whose absolute error (half an ulp of 1) is then also a
+// relative error of at most 2^-22 of the value (it is >= 1/3).  With a fixed pair (b0, b1) a sliver fragment's
+// b2 ~ 1e-4 would come back with a relative error of 1e-3, which is what the per-element gradient tolerance
+// (tests/parity.py) sees.  The choice is carried in the two SIGN bits (barycentrics of a covered sample are >= 0):
+//   code 0: (p, q) = (b0, b1), b2 derived;  sign(p) set = code 1: (b1, b2), b0 derived;  sign(q) set = code 2: (b2, b0), b1 derived.
+__device__ __forceinline__ float2 encode_bary(float b0, float b1, float b2)
+{
+    const bool omit2 = (b2 >= b0) & (b2 >= b1);
+    const bool omit0 = !omit2 & (b0 >= b1);
+    const bool omit1 = !omit2 & !omit0;
+    const float p = omit2 ? b0 : (omit0 ? b1 : b2);
+    const float q = omit2 ? b1 : (omit0 ? b2 : b0);
+    return make_float2(__uint_as_float(__float_as_uint(p) | (omit0 ? 0x80000000u : 0u)),
+                       __uint_as_float(__float_as_uint(q) | (omit1 ? 0x80000000u : 0u)));
+}
+__device__ __forceinline__ void decode_bary(float2 e, float (&b)[3])
+{
+    const bool sp = (int32_t)__float_as_uint(e.x) < 0, sq = (int32_t)__float_as_uint(e.y) < 0;
+    const float P = fabsf(e.x), Q = fabsf(e.y);
+    const float d = (1.f - P) - Q;
+    b[0] = sq ? Q : (sp ? d : P);
+    b[1] = sq ? d : (sp ? P : Q);
+    b[2] = sq ? P : (sp ? Q : d);
+}
+
 // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8); give every XCD a
 // contiguous run of tiles (a band of tile rows) so neighbouring tiles, which share faces, hit the
 // same L2, and the backward pass reads a band's visibility / fragments / pixels on the XCD

@@ -4,7 +4,8 @@
 // evaluating every channel group of dirt/rasterise_ops.py:145-165 inside one launch, the N
 // per-group RasteriseGrad ops (and N GL re-draws) the reference issues for C not in {1,3}.
 //
-// Input: the per-pixel state the raster kernel leaves behind -- two float2 planes, {clip_w, face} and {b0, b1}, the
+// Input: the per-pixel state the raster kernel leaves behind -- two float2 planes, {clip_w, face} and two of the three
+// barycentrics (encode_bary, dirt_device.h), the
 // counterpart of the reference's two RGBA32F surfaces (csrc/rasterise_grad_egl.cpp:432-456), produced by the forward
 // pass itself when it keeps its state -- plus `faces` for the vertex indices.
 //
@@ -327,13 +328,10 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             s_vw[row][v_ci + 1] = rec[k];
         }
     }
-    // own barycentrics b0, b1
+    // own barycentrics (two stored, the largest re-derived: decode_bary)
     float bk[4][3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float2 q = ld_off<float2>(state_b, in_px[j] ? (own_rel + (uint32_t)j) * 8u : 0u);
-        bk[j][0] = q.x; bk[j][1] = q.y; bk[j][2] = (1.f - q.x) - q.y;
-    }
+    for (int j = 0; j < 4; ++j) decode_bary(ld_off<float2>(state_b, in_px[j] ? (own_rel + (uint32_t)j) * 8u : 0u), bk[j]);
     zero_inbox();
 
     // (fx, fy) sent to this strip's own pixels by themselves (see "position factors" below)
@@ -528,7 +526,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                     const int py = y0 + 8 * wave + ty, px = x0 + tx;
                     lkey[e] = __float_as_int(s_vw[8 * wave + ty + 1][tx + 2].y);
                     const float2 nb = ld_off<float2>(state_b, (uint32_t)((py - row0) * W + px) * 8u);
-                    lb[e][0] = nb.x; lb[e][1] = nb.y; lb[e][2] = (1.f - nb.x) - nb.y;
+                    decode_bary(nb, lb[e]);
                     const float ndc_x = ((float)px + 0.5f) * p.two_over_w - 1.f;
                     const float ndc_y = ((float)(H - 1 - py) + 0.5f) * p.two_over_h - 1.f;
                     lf[e][0] = v.x; lf[e][1] = v.y; lf[e][2] = -(v.x * ndc_x + v.y * ndc_y);

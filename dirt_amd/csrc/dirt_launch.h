@@ -55,7 +55,7 @@ struct RasterParams {
     float* pixels;               // [B,H,W,C]
     int32_t* vis;                // [B,H,W] front-most face per pixel (dirt_rasterise_visibility's output); or nullptr
     float2* state_a;             // [B,H,W] {clip_w, face} and ...
-    float2* state_b;             // [B,H,W] {b0, b1} of the front-most fragment: what the backward pass reads; or nullptr (both)
+    float2* state_b;             // [B,H,W] two of the three barycentrics of the front-most fragment (encode_bary): what the backward pass reads; or nullptr (both)
     int V, F, H, W, C;
     BinGrid grid;
     unsigned flags;              // DIRT_FLAG_TILES_*
@@ -64,7 +64,7 @@ struct RasterParams {
 
 struct GradParams {
     const float2* state_a;     // [B,H,W] {clip_w, face} and
-    const float2* state_b;     // [B,H,W] {b0, b1}: the backward fragment shader's output (csrc/shaders.cpp:64-77) with
+    const float2* state_b;     // [B,H,W] two barycentrics (encode_bary): the backward fragment shader's output (csrc/shaders.cpp:64-77) with
                                //         b2 = 1 - b0 - b1 and the face index (bit pattern) in place of the index triple
     const int32_t* faces;      // [B,F,3], or [F,3] when shared_faces
     int shared_faces;

@@ -285,12 +285,13 @@ __device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec
     }
 }
 
-// The backward pass's state of one pixel -- csrc/shaders.cpp:64-77: {clip_w, face} and {b0, b1} (b2 = 1 - b0 - b1; the
-// face index stands for the index triple) -- or the clear values of csrc/rasterise_grad_egl.cpp:442-445.
-__device__ __forceinline__ void store_state(const RasterParams& p, size_t pix, float b0, float b1, float clip_w, int32_t face)
+// The backward pass's state of one pixel -- csrc/shaders.cpp:64-77: {clip_w, face} and two of the three barycentrics
+// (encode_bary, dirt_device.h; the face index stands for the index triple) -- or the clear values of
+// csrc/rasterise_grad_egl.cpp:442-445.
+__device__ __forceinline__ void store_state(const RasterParams& p, size_t pix, bool has, float b0, float b1, float b2, float clip_w, int32_t face)
 {
-    p.state_a[pix] = make_float2(clip_w, __int_as_float(face));
-    p.state_b[pix] = make_float2(b0, b1);
+    p.state_a[pix] = make_float2(has ? clip_w : INFINITY, __int_as_float(face));
+    p.state_b[pix] = has ? encode_bary(b0, b1, b2) : make_float2(-1.f, -1.f);
 }
 
 // raster_kernel<MODE, NB, CSPEC>: MODE 0 renders (pixels, and the backward pass's state when p.state_a), MODE 1 is the
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
         if (!inside[k]) continue;
         // the backward pass's state and the visibility export
         if (p.vis) p.vis[pix[k]] = f;
-        if (p.state_a) store_state(p, pix[k], has ? b0 : -1.f, has ? b1 : -1.f, has ? cw : INFINITY, f);
+        if (p.state_a) store_state(p, pix[k], has, b0, b1, b2, cw, f);
         if (MODE != 0) continue;
         float* __restrict__ out = p.pixels + pix[k] * C;
         if (CSPEC != 0) {
