@@ -8,8 +8,13 @@ HBM.  Rank 0 prints ONE JSON line.
 
 Workload: BASELINE.json's metric config K3 -- a 10 000-triangle random mesh rendered at
 1024x1024x4 channels (SURVEY.md 8d `rand_mesh`, seed 0 + scene index), `--scenes-per-gpu` scenes per
-rank (default 1 = K3 itself; 8 per rank on 8 GPUs is K4).  Scenes are independent, so ranks share
-nothing on the data path (weak scaling, no collective inside the timed region; DESIGN.md "Multi-GPU").
+rank: 1 by default AT EVERY N (K3 itself on each GPU), so that value(N) / value(1) is weak scaling of one
+and the same per-GPU workload; `--scenes-per-gpu 8 --gpus 8` is K4 (64 scenes over 8 GPUs) and
+`--scenes-per-gpu 64 --gpus 1` K4 on one GPU.  Scenes are independent, so ranks share nothing on the data
+path (no collective inside the timed region; DESIGN.md "Multi-GPU").  At N > 1 rank 0 also times the
+same per-GPU workload ALONE (the other ranks idle at a barrier) and prints it as `scaling_reference`;
+`--gather` times, separately from the render, the collection of all ranks' pixels on rank 0 over RCCL
+("report the gathered variant separately").
 
 Extra objects on the JSON line:
   roofline     -- the dominant kernel (by summed HIP-event time over the timed steps) against the HBM
@@ -65,11 +70,18 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--scenes-per-gpu', type=int, default=0,
-                    help='scenes rendered per rank and step (default: 1 on one GPU = K3 itself; 8 on several = K4, 64 scenes over 8 GPUs)')
+    ap.add_argument('--scenes-per-gpu', type=int, default=1,
+                    help='scenes rendered per rank and step (default 1 at every N: K3 itself per GPU; 8 on 8 GPUs = K4)')
+    ap.add_argument('--gather', action='store_true',
+                    help='also time gather_batch of every rank\'s pixels to rank 0 (outside the render timing; N > 1)')
+    ap.add_argument('--traffic', default='auto', choices=['auto', 'measure', 'file', 'off'],
+                    help='roofline.traffic: measured in this run with rocprofv3 --pmc passes (auto: when rocprofv3 is on PATH and N = 1), '
+                         'or read from profiles/pmc_traffic.json if its source stamp matches the tree')
     ap.add_argument('--config', default='K3', help='K3 | K3-256 | K3-2048 | K5')
-    ap.add_argument('--launch', default='auto', choices=['auto', 'eager', 'graph'],
-                    help='how the timed steps are issued: eagerly, as one captured hipGraph replayed per step, or whichever a short calibration finds faster')
+    ap.add_argument('--launch', default='eager', choices=['auto', 'eager', 'graph'],
+                    help='how the timed steps are issued: eagerly through the Python wrapper and the C ABI (default: what an autograd user '
+                         'pays), as one captured hipGraph replayed per step, or whichever a short calibration finds faster; both are '
+                         'reported either way (ms_per_step_eager / ms_per_step_graph)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
     args = ap.parse_args()
@@ -103,7 +115,7 @@ def main():
     _lib.load()
 
     F, H, W, C, seed0, r_lo, r_hi = scenes.CONFIGS[args.config]
-    spg = args.scenes_per_gpu or (8 if distributed else 1)
+    spg = max(1, args.scenes_per_gpu)
     seeds = [seed0 + rank * spg + i for i in range(spg)]
     batch = scenes.batch_scene(F, H, W, C, seeds, r_lo=r_lo, r_hi=r_hi)
     V = batch['vertices'].shape[1]
@@ -145,7 +157,7 @@ def main():
         return (time.perf_counter() - c0) / n
 
     graph_replay = None
-    if args.launch != 'eager':
+    if True:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -157,11 +169,12 @@ def main():
         with torch.cuda.graph(graph):
             graph_out = step()
         graph_replay = graph.replay
-    calib = {}
+    # both ways are always timed (a short region each, after a warm-up) and reported; the headline follows --launch
+    for _ in range(5):
+        step(); graph_replay()
+    n_cal = max(20, min(args.steps, 100))
+    calib = {'eager_ms_per_step': timed(step, n_cal) * 1e3, 'graph_ms_per_step': timed(graph_replay, n_cal) * 1e3, 'steps': n_cal}
     if args.launch == 'auto':
-        for _ in range(5):
-            step(); graph_replay()
-        calib = {'eager_ms_per_step': timed(step, 20) * 1e3, 'graph_ms_per_step': timed(graph_replay, 20) * 1e3}
         use_graph = calib['graph_ms_per_step'] < calib['eager_ms_per_step']
         if distributed:  # every rank takes rank 0's choice
             flag = torch.tensor([1 if use_graph else 0], device=dev)
@@ -187,6 +200,44 @@ def main():
     total_pixels = world * spg * P
     value = total_pixels / (elapsed / args.steps) / 1e6
 
+    # ---- N > 1: the same per-GPU workload on rank 0 ALONE (every other rank idles at the barrier), so that the line
+    #      carries its own one-GPU reference for exactly this scenes-per-GPU count ----
+    scaling_reference = None
+    if distributed:
+        dist.barrier()
+        if rank == 0:
+            for _ in range(min(args.warmup, 20)):
+                run()
+            n_ref = max(20, min(args.steps, 200))
+            t_ref = timed(run, n_ref)
+            scaling_reference = {'n_gpus': 1, 'scenes_per_gpu': spg, 'steps': n_ref, 'ms_per_step': t_ref * 1e3,
+                                 'value': spg * P / t_ref / 1e6, 'unit': 'Mpixels/s',
+                                 'note': 'rank 0 alone, the other ranks idle; value / (n_gpus * this) is the weak-scaling efficiency'}
+        dist.barrier()
+
+    # ---- optional: collecting every rank's pixels on rank 0 (grouped send / recv over RCCL, dirt_amd/sharding.py), timed
+    #      on its own -- it is per-link bound over xGMI and never part of the render timing ----
+    gather = None
+    if args.gather and distributed:
+        from dirt_amd import sharding
+        px = ops._op_rasterise(bg, v, vc, f, H, W, C)
+        for _ in range(2):
+            sharding.gather_batch(px, world * spg, 0)
+        barrier()
+        n_g = 10
+        c0 = time.perf_counter()
+        for _ in range(n_g):
+            full = sharding.gather_batch(px, world * spg, 0)
+        barrier()
+        t_g = (time.perf_counter() - c0) / n_g
+        tg = torch.tensor([t_g], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        nbytes = (world - 1) * spg * P * C * 4
+        gather = {'what': 'pixels of all %d scenes to rank 0' % (world * spg), 'ms': float(tg.item()) * 1e3, 'bytes_received': nbytes,
+                  'GB_per_s': nbytes / float(tg.item()) / 1e9,
+                  'render_plus_gather_value': total_pixels / (elapsed / args.steps + float(tg.item())) / 1e6,
+                  'rank0_has_all': bool(rank != 0 or (full is not None and full.shape[0] == world * spg))}
+
     # ---- per-kernel HIP-event timing over a second, identical timed region (rank 0 only) ----
     roofline = None
     kernels = {}
@@ -198,31 +249,59 @@ def main():
         torch.cuda.synchronize()
         prof = _lib.profile_read()
         kbytes = kernel_algorithmic_bytes(P, V, F, C)
+        # An event pair around a launch reads ~2 us longer than the kernel runs (the closing event's packet is processed after
+        # the kernel has drained): the raw readings of a step sum to MORE than the step takes.  The excess, shared equally
+        # among the step's launches, is taken off each reading -- a lower bound of the true overhead (the step also contains
+        # the gaps between kernels), so the corrected times are upper bounds of rocprofv3's and sum to <= the eager step.
+        raw_us = {name: ms / n * 1e3 for name, (ms, n) in prof.items() if n}
+        launches = sum(n for _, n in prof.values()) / args.steps
+        eager_step_us = (ms_per_step if not use_graph else calib['eager_ms_per_step']) * 1e3
+        sum_raw = sum(ms for ms, _ in prof.values()) / args.steps * 1e3
+        pair_us = max(0.0, (sum_raw - eager_step_us) / launches) if launches else 0.0
         for name, (ms, n) in prof.items():
             if n:
-                kernels[name] = {'launches_per_step': n / args.steps, 'avg_us': ms / n * 1e3,
-                                 'us_per_step': ms / args.steps * 1e3}
+                raw = raw_us[name]
+                kernels[name] = {'launches_per_step': n / args.steps, 'avg_us': max(raw - pair_us, 0.0), 'avg_us_event_pair': raw,
+                                 'us_per_step': max(raw - pair_us, 0.0) * n / args.steps}
         dom = max(kernels, key=lambda k: kernels[k]['us_per_step'])
         avg_s = kernels[dom]['avg_us'] * 1e-6
         per_launch = kbytes[dom] * spg
         achieved = per_launch / avg_s / 1e9
-        traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')  # written by tools/pmc_summary.py from rocprofv3 --pmc passes
-        if os.path.exists(pmc):
+        traffic, traffic_source, traffic_all = None, None, None
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import measure_traffic
+        want_measure = args.traffic == 'measure' or (args.traffic == 'auto' and world == 1 and spg == 1)
+        if want_measure:
             try:
-                pj = json.load(open(pmc))
-                traffic = pj.get(args.config, {}).get(dom)
-                if traffic is not None:
-                    traffic *= spg   # counted on one scene per launch; a launch of this run renders `spg` independent scenes
-                    traffic_source = ('profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of one scene of this workload'
-                                      '%s, not measured in this run' % (pj.get('_collected', 'committed'), ' x %d scenes per launch' % spg if spg > 1 else ''))
+                traffic_all = measure_traffic.measure(args.config)
+                traffic = traffic_all.get(dom)
+                traffic_source = ('measured in this run: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes) over 3 steps of this '
+                                  'workload, (2 * FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 correction of MI355X_MICROARCH.md)')
+            except Exception as e:  # no rocprofv3, no permission, time-out: fall back to the stamped file
+                traffic_source = 'in-run measurement failed (%s)' % (str(e)[:80],)
+        if traffic is None and args.traffic != 'off':
+            pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')  # written by tools/measure_traffic.py
+            try:
+                pj = json.load(open(pmc)).get(args.config, {})
+                if pj.get('_sources_sha256') == measure_traffic.source_stamp():
+                    traffic = pj.get(dom)
+                    if traffic is not None:
+                        traffic *= spg   # counted on one scene per launch; a launch of this run renders `spg` independent scenes
+                        traffic_source = ((traffic_source + '; ' if traffic_source else '') +
+                                          'profiles/pmc_traffic.json, collected on these very kernel sources (sha256 stamp matches)'
+                                          + (' x %d scenes per launch' % spg if spg > 1 else ''))
+                else:
+                    traffic_source = (traffic_source + '; ' if traffic_source else '') + 'profiles/pmc_traffic.json is stale (source stamp differs): not used'
             except Exception:
-                traffic = None
+                pass
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                     'frac': achieved / HBM_PEAK_GBPS, 'frac_of_measured_copy_peak': achieved / HBM_COPY_GBPS,
-                    'traffic': traffic, 'traffic_source': traffic_source,
+                    'traffic': traffic, 'traffic_source': traffic_source, 'traffic_all_kernels': traffic_all,
                     'algorithmic_bytes_per_launch': per_launch, 'avg_launch_us': kernels[dom]['avg_us'],
-                    'timing': 'HIP events recorded by the library around each launch on its stream (DIRT_FLAG_PROFILE), eager steps'}
+                    'avg_launch_us_with_event_pair': kernels[dom]['avg_us_event_pair'], 'event_pair_us': pair_us,
+                    'timing': 'HIP events recorded by the library around each launch on its stream (DIRT_FLAG_PROFILE), eager steps; '
+                              'event_pair_us = (sum of the raw readings of a step - the eager step time) / launches per step is taken '
+                              'off every reading (a lower bound of what an event pair adds: the result never undercuts the kernel trace)'}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N == 1) ----
     cpu_baseline = None
@@ -249,7 +328,7 @@ def main():
                 best, cores = dt, n
         oracle.set_num_threads(cores)
         n_it, t_cpu = 0, 0.0
-        while t_cpu < args.cpu_seconds and n_it < 20:
+        while t_cpu < args.cpu_seconds and n_it < 400:
             c0 = time.perf_counter()
             px = oracle.forward(one['background'], one['vertices'], one['vertex_colors'], one['faces'])
             oracle.backward(one['vertices'], one['faces'], px, one['grad_pixels'])
@@ -273,7 +352,10 @@ def main():
                        'scenes_per_gpu': spg, 'parallelism': 'batch-sharded x%d, no collective' % world,
                        'launch': 'one captured hipGraph replayed per step' if use_graph else 'eager (Python wrapper + C ABI per step)'},
             'ranks_seen': ranks_seen,
+            'ms_per_step_eager': calib['eager_ms_per_step'], 'ms_per_step_graph': calib['graph_ms_per_step'],
             'launch_calibration': calib,
+            'scaling_reference': scaling_reference,
+            'gather': gather,
             'roofline': roofline,
             'roofline_step': {'algorithmic_bytes': step_bytes, 'achieved': step_bytes / (ms_per_step * 1e-3) / 1e9,
                               'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

@@ -13,6 +13,7 @@ Differences from the reference, by design:
     evaluation (dirt/rasterise_ops.py:86-108,132-177), which issues one op per group;
   * the deferred wrappers rasterise visibility once per gradient call instead of once per group.
 """
+import collections
 import ctypes
 
 import torch
@@ -21,17 +22,25 @@ from . import _lib
 
 __all__ = ['rasterise', 'rasterise_batch', 'rasterise_deferred', 'rasterise_batch_deferred']
 
-_workspaces = {}
+_WORKSPACE_SLOTS = 4   # scratch buffers kept per process: the most recently used (device, stream) pairs
+_workspaces = collections.OrderedDict()
 
 
 def _workspace(device, nbytes):
-    """Grow-only scratch per (device, stream); the analogue of the reference's grow-only GL buffers
-    (csrc/rasterise_egl.cpp:325-333), but owned by the caller's allocator, not by the library."""
+    """Grow-only scratch per (device, stream) -- the analogue of the reference's grow-only GL buffers
+    (csrc/rasterise_egl.cpp:325-333), but owned by the caller's allocator, not by the library -- for the calls that keep
+    no state (inference, `_op_visibility`, the stateless backward).  At most _WORKSPACE_SLOTS of them are kept (least
+    recently used first out): a long job that creates streams as it goes does not accumulate one buffer per stream
+    handle it ever saw.  An evicted buffer goes back to torch's caching allocator, which keeps it alive until the work
+    already queued on its stream has run (it was allocated on that stream)."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
+    _workspaces.move_to_end(key)
+    while len(_workspaces) > _WORKSPACE_SLOTS:
+        _workspaces.popitem(last=False)
     return ws
 
 
@@ -147,6 +156,10 @@ def _op_rasterise(background, vertices, vertex_colors, faces, height, width, cha
         if keep_state:
             if state_channels > channels:
                 nbytes = _workspace_bytes(lib, B, V, F, height, width, state_channels)
+            # one state per autograd forward (it must outlive the call, until its backward).  torch's caching allocator is
+            # the free list: the block of a state whose graph has died is handed out again for the next forward of the
+            # same size, so a training loop cycles through one or two blocks and reserved memory stays flat
+            # (tools/soak.py asserts that over 10 000 steps).
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             flags |= _lib.FLAG_KEEP_STATE
         else:
@@ -271,6 +284,12 @@ class _Rasterise(torch.autograd.Function):
         grad_background, grad_vertices, grad_vertex_colors, _ = _op_rasterise_grad(
             vertices, faces, pixels, grad_pixels.to(torch.float32), height, width, channels, state=ctx.state,
             state_outputs=first)
+        if first:
+            # the state's accumulators are interleaved (one row {x, y, z, w, colours} per vertex): hand autograd DENSE
+            # tensors, as the reference's op returns -- strided views would pin the whole state (records + 16 bytes per
+            # pixel) for as long as a gradient lives, make `.view(-1)` raise, and be cloned by AccumulateGrad anyway
+            grad_vertices = grad_vertices.contiguous()
+            grad_vertex_colors = grad_vertex_colors.contiguous()
         return grad_background, grad_vertices, grad_vertex_colors, None, None, None, None  # None wrt faces
 
 
@@ -333,7 +352,14 @@ def _rasterise_grad_multichannel(vertices, faces, pixels, d_loss_by_pixels, sing
     return {'grad_vertices': gv, 'grad_vertex_colors': gvc, 'grad_background': gb}
 
 
-def _unlisted_leaves(output, listed, limit=20000):
+_checked_shaders = set()   # code objects of the shader functions whose graphs have been walked once
+
+
+def _shader_key(shader_fn):
+    return getattr(shader_fn, '__code__', None) or getattr(getattr(shader_fn, '__call__', None), '__code__', None) or id(shader_fn)
+
+
+def _unlisted_leaves(output, listed, limit=2000):
     """Leaf tensors that `output` depends on (requires_grad) and that are not in `listed`: parameters a shader closes over
     without naming them in `shader_parameters`.  TensorFlow's custom_gradient hands those to the gradient function as
     `variables` (dirt/rasterise_ops.py:239-246); a torch.autograd.Function cannot, so they would silently get no gradient."""
@@ -377,7 +403,10 @@ class _RasteriseDeferred(torch.autograd.Function):
             extra_in = [t.detach().requires_grad_(t.is_floating_point()) if isinstance(t, torch.Tensor) else t
                         for t in shader_additional_inputs]
             pixels = shader_fn(gbuffer_in, *extra_in)
-        stray = _unlisted_leaves(pixels, [gbuffer_in] + list(extra_in) + list(shader_params))
+        # (the graph walk is a debugging aid with a host-side cost: done on the first call of each shader function only)
+        key = _shader_key(shader_fn)
+        stray = [] if key in _checked_shaders else _unlisted_leaves(pixels, [gbuffer_in] + list(extra_in) + list(shader_params))
+        _checked_shaders.add(key)
         if stray:
             import warnings
             warnings.warn('rasterise_deferred: shader_fn uses %d tensor(s) that require grad but are neither '

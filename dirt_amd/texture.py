@@ -109,4 +109,10 @@ def sample_texture_uv(texture, uvs, mode='repeat', filter='bilinear'):
     (samples/textured.py:16-61, as its shader_fn uses them, :116-141): texture [Ht, Wt, C] float32, uvs [*, 2] with
     (0, 0) at the top-left of the image -> [*, C].  Differentiable with respect to the texture and the coordinates."""
     flags = {'repeat': 0, 'clamp': _lib.TEX_CLAMP}[mode] | {'bilinear': 0, 'nearest': _lib.TEX_NEAREST}[filter]
+    if texture.dim() != 3:
+        raise ValueError('sample_texture_uv expects texture to be 3D [height, width, channels], got shape %s' % (tuple(texture.shape),))
+    if uvs.dim() < 1 or uvs.shape[-1] != 2:
+        raise ValueError('sample_texture_uv expects uvs of shape [..., 2], got %s' % (tuple(uvs.shape),))
+    if texture.device != uvs.device:
+        raise ValueError('texture and uvs must be on the same device (%s vs %s)' % (texture.device, uvs.device))
     return _SampleTextureUV.apply(texture.to(torch.float32), uvs.to(torch.float32), flags)

@@ -117,6 +117,21 @@ def test_autograd_wiring(gpu, oracle):
     _assert_grad_close(vc.grad.cpu().numpy(), ow, 'grad_vertex_colors', 'autograd gvc', 0)
 
 
+def test_autograd_gradients_are_dense(gpu):
+    """The reference's grad op returns dense tensors; so does the autograd path here (the state's interleaved accumulators
+    are an internal layout): `.view(-1)` works and the gradients do not alias each other or a workspace."""
+    s = scenes.rand_scene(80, 40, 56, 4, 32, 0.05, 0.3)
+    bg = _t(s['background'], gpu).requires_grad_(True)
+    v = _t(s['vertices'], gpu).requires_grad_(True)
+    vc = _t(s['vertex_colors'], gpu).requires_grad_(True)
+    px = ops.rasterise(bg, v, vc, _t(s['faces'], gpu))
+    gb, gv, gvc = torch.autograd.grad(px, [bg, v, vc], _t(s['grad_pixels'], gpu))
+    for t_ in (gb, gv, gvc):
+        assert t_.is_contiguous()
+        assert t_.view(-1).numel() == t_.numel()
+    assert gv.untyped_storage().nbytes() == gv.numel() * 4 and gvc.untyped_storage().nbytes() == gvc.numel() * 4
+
+
 def test_empty_inputs(gpu):
     bg = torch.rand(2, 16, 16, 3, device=gpu)
     out = ops.rasterise_batch(bg, torch.zeros(2, 0, 4, device=gpu), torch.zeros(2, 0, 3, device=gpu),

@@ -88,3 +88,13 @@ def test_fused_lookup_gradients_in_place_from_a_gbuffer(gpu, mode):
     texture.sample_texture(t2, texture.uvs_to_pixel_indices(gb2[..., 1:3], t2.shape[:2], mode)).backward(torch.from_numpy(g).to(gpu))
     assert torch.allclose(t.grad, t2.grad, atol=1e-4, rtol=1e-4)
     assert torch.allclose(gb.grad, gb2.grad, atol=1e-3, rtol=1e-4)
+
+
+def test_argument_shapes_are_checked():
+    """`[..., 3]` coordinates or a 2-D texture are refused instead of being read as the wrong pairs (no GPU needed: the
+    checks come before any device work)."""
+    from dirt_amd import texture as tex
+    with pytest.raises(ValueError):
+        tex.sample_texture_uv(torch.zeros(4, 4, 3), torch.zeros(5, 3))
+    with pytest.raises(ValueError):
+        tex.sample_texture_uv(torch.zeros(4, 4), torch.zeros(5, 2))
