@@ -82,6 +82,7 @@ def main():
                     help='how the timed steps are issued: eagerly through the Python wrapper and the C ABI (default: what an autograd user '
                          'pays), as one captured hipGraph replayed per step, or whichever a short calibration finds faster; both are '
                          'reported either way (ms_per_step_eager / ms_per_step_graph)')
+    ap.add_argument('--flags', type=lambda x: int(x, 0), default=0, help='extra DIRT_FLAG_* bits for every call (kernel-shape experiments)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
     args = ap.parse_args()
@@ -127,6 +128,7 @@ def main():
     bg, v, vc, f, g = (t(batch[k]) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels'))
 
     def step(flags=0):
+        flags |= args.flags
         # exactly what torch.autograd does through dirt_amd.rasterise_batch: the forward leaves its
         # set-up records + visibility in a private state buffer, the backward consumes it
         px, state = ops._op_rasterise(bg, v, vc, f, H, W, C, flags=flags, keep_state=True)

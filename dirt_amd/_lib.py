@@ -21,6 +21,7 @@ FLAG_TILES_SMALL = 0x400
 FLAG_SHARED_FACES = 0x800
 FLAG_GRAD_ROWS = 0x1000    # gradient kernel: every 8x8 block walks its own faces (default for small frames)
 FLAG_GRAD_PAIRS = 0x2000   # ... or pairs of blocks share a face (default otherwise)
+FLAG_GRAD_SMALL = 0x4000   # ... or the one-pixel-per-lane kernel on 16x16 tiles (default for small frames with 1, 3 or 4 channels)
 TEX_CLAMP = 1
 TEX_NEAREST = 2
 

@@ -89,5 +89,6 @@ hipError_t launch_zero(void* b, size_t b_bytes, void* c, size_t c_bytes, hipStre
 hipError_t launch_geometry(const GeomParams& g, hipStream_t stream);
 hipError_t launch_raster(const RasterParams& p, int B, bool visibility_only, hipStream_t stream);
 hipError_t launch_grad(const GradParams& p, hipStream_t stream);
+hipError_t launch_grad_small(const GradParams& p, hipStream_t stream);  // dirt_grad_small.hip; p as filled by launch_grad
 
 }  // namespace dirt

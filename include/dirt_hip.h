@@ -61,11 +61,14 @@ extern "C" {
 #define DIRT_FLAG_TILES_LARGE 0x200u /* pin the forward / visibility kernels' tile shape instead of letting the library
                                        choose it from the frame size and the face density: 32x32 pixel tiles ... */
 #define DIRT_FLAG_TILES_SMALL 0x400u /* ... or 16x16.  Results do not depend on the shape (pixels and visibility bit for
-                                       bit); for tests.  The gradient kernel always works on 32x32 tiles. */
+                                       bit); for tests.  (The gradient kernel's shapes: DIRT_FLAG_GRAD_*.) */
 #define DIRT_FLAG_GRAD_ROWS 0x1000u  /* pin the gradient kernel's face-loop shape instead of letting the library choose by
                                         frame size: every 8x8 block of a wave walks its own faces ... */
 #define DIRT_FLAG_GRAD_PAIRS 0x2000u /* ... or pairs of blocks share a face (fewer float atomics).  Results agree to
                                         summation order (how the parity tests cover both) */
+#define DIRT_FLAG_GRAD_SMALL 0x4000u /* ... or the small-frame gradient kernel: one pixel per lane on 16x16 tiles
+                                        (channel counts 1, 3, 4; chosen by the library for frames of at most 256 32x32
+                                        tiles).  Same results to summation order */
 #define DIRT_FLAG_SHARED_FACES 0x800u /* `faces` is one [F,3] topology shared by all B scenes instead of [B,F,3] (the
                                         TODO of csrc/rasterise_egl.cpp:314).  Same flag on the
                                         forward, visibility and backward calls of one scene batch. */

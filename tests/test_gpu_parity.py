@@ -31,7 +31,8 @@ def _fwd_gpu(s, dev, flags=0):
 # The library picks the kernels' tile shape from the frame size and the face density; small test frames would
 # only ever see the small shape, so the parity tests pin each shape in turn (DIRT_FLAG_TILES_*).
 # (the tile-shape flags of the forward kernels, each with one of the gradient kernel's face-loop shapes pinned as well)
-TILE_SHAPES = [pytest.param(0, id='auto'), pytest.param(0x200 | 0x2000, id='large-tiles'), pytest.param(0x400 | 0x1000, id='small-tiles')]
+TILE_SHAPES = [pytest.param(0, id='auto'), pytest.param(0x200 | 0x2000, id='large-tiles'), pytest.param(0x400 | 0x1000, id='small-tiles'),
+               pytest.param(0x400 | 0x4000, id='small-tiles-px1')]
 
 
 def _assert_grad_close(got, ow, key, what, index=None):

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
   -fhip-fp32-correctly-rounded-divide-sqrt -munsafe-fp-atomics -Wall -Wno-unused-function "$@" \
-  dirt_amd/csrc/dirt_capi.hip dirt_amd/csrc/dirt_raster.hip dirt_amd/csrc/dirt_grad.hip dirt_amd/csrc/dirt_texture.hip -o /tmp/_res.so \
+  dirt_amd/csrc/dirt_capi.hip dirt_amd/csrc/dirt_raster.hip dirt_amd/csrc/dirt_grad.hip dirt_amd/csrc/dirt_grad_small.hip dirt_amd/csrc/dirt_texture.hip -o /tmp/_res.so \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import sys,re,subprocess
 cur=None; rows={}
