@@ -253,8 +253,9 @@ def main():
         kbytes = kernel_algorithmic_bytes(P, V, F, C)
         # An event pair around a launch reads ~2 us longer than the kernel runs (the closing event's packet is processed after
         # the kernel has drained): the raw readings of a step sum to MORE than the step takes.  The excess, shared equally
-        # among the step's launches, is taken off each reading -- a lower bound of the true overhead (the step also contains
-        # the gaps between kernels), so the corrected times are upper bounds of rocprofv3's and sum to <= the eager step.
+        # among the step's launches, is taken off each reading (the step also contains the gaps between kernels, so this
+        # does not over-correct by more than those): the corrected times sum to the eager step and agree with rocprofv3's
+        # kernel trace of the same command within ~3 % (profiles/README.md).
         raw_us = {name: ms / n * 1e3 for name, (ms, n) in prof.items() if n}
         launches = sum(n for _, n in prof.values()) / args.steps
         eager_step_us = (ms_per_step if not use_graph else calib['eager_ms_per_step']) * 1e3
@@ -303,7 +304,7 @@ def main():
                     'avg_launch_us_with_event_pair': kernels[dom]['avg_us_event_pair'], 'event_pair_us': pair_us,
                     'timing': 'HIP events recorded by the library around each launch on its stream (DIRT_FLAG_PROFILE), eager steps; '
                               'event_pair_us = (sum of the raw readings of a step - the eager step time) / launches per step is taken '
-                              'off every reading (a lower bound of what an event pair adds: the result never undercuts the kernel trace)'}
+                              'off every reading (agrees with the rocprofv3 kernel trace of the same command within ~3 %: profiles/)'}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N == 1) ----
     cpu_baseline = None

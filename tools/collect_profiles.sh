@@ -2,11 +2,11 @@
 # Runs on the GPU box (gpurun): rocprofv3 kernel-trace stats of bench.py, then separate --pmc passes
 # (never combined with tracing options) for instruction mix, LDS and HBM traffic.  Output: gpurun_out/prof_$1/
 set -u
-TAG=${1:-r01}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-BENCH="python bench.py --steps 50 --warmup 10 --no-cpu-baseline"
+BENCH="python bench.py --steps 50 --warmup 10 --no-cpu-baseline --traffic off"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 RUN="python tools/prof_run.py K3 5"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sq -o pmc -- $RUN > /dev/null 2>&1
@@ -15,14 +15,19 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACT
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $RUN > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $RUN > /dev/null 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -o pmc -- $RUN > /dev/null 2>&1
-python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.log
+# the default bench line (in-run traffic measurement, CPU baseline), then the other configurations
+python bench.py > $OUT/bench.json 2> $OUT/bench.log
 for cfg in K3-256 K3-2048 K5; do
-  python bench.py --config $cfg --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_$cfg.json 2>> $OUT/bench.log
+  python bench.py --config $cfg --steps 100 --warmup 20 --no-cpu-baseline > $OUT/bench_$cfg.json 2>> $OUT/bench.log
 done
 python bench.py --scenes-per-gpu 8 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_K3x8.json 2>> $OUT/bench.log
-# the K5 gradient pass is the traffic-bound one: its own counters
+python bench.py --scenes-per-gpu 64 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_K4x1.json 2>> $OUT/bench.log
+# kernel trace of the small-frame step (the one-pixel-per-lane gradient kernel) and of K5
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_K3-256 -o trace -- python tools/prof_run.py K3-256 50 > /dev/null 2>&1
 RUN5="python tools/prof_run.py K5 3"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_K5 -o trace -- $RUN5 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_K5 -o pmc -- $RUN5 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_K5 -o pmc -- $RUN5 > /dev/null 2>&1
-ls -R $OUT | head -40
+# HBM traffic per launch, stamped with the kernel sources' hash (profiles/pmc_traffic.json is rewritten in place)
+python tools/measure_traffic.py K3 K3-256 K5 > $OUT/traffic.log 2>&1
+cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
+timeout 300 python tools/soak.py 10000 > $OUT/soak.log 2>&1
+ls -R $OUT | head -60

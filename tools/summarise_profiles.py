@@ -2,8 +2,8 @@
    profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python bench.py --steps 50 --warmup 10`
    profiles/<tag>_pmc.txt            per-kernel PMC averages (separate --pmc passes)
    profiles/<tag>_bench.json         the bench line of the same build
-   profiles/pmc_traffic.json         HBM bytes per launch per kernel, FETCH_SIZE doubled as
-                                     /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950
+   profiles/pmc_traffic.json         HBM bytes per launch per kernel (tools/measure_traffic.py on the box: FETCH_SIZE doubled as
+                                     /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950; stamped with the sources' sha256)
 usage: python tools/summarise_profiles.py r01 [config]"""
 import collections
 import csv
@@ -61,39 +61,19 @@ def main():
         if name != 'under_rocprof' and lines:
             json.dump(json.loads(lines[-1]), open(os.path.join(dst, '%s_bench_%s.json' % (tag, name)), 'w'), indent=1)
 
-    def traffic_of(suffix):
-        fetch = counter(glob.glob(os.path.join(src, 'pmc_fetch' + suffix, '*counter_collection.csv'))[0], 'FETCH_SIZE')
-        write = counter(glob.glob(os.path.join(src, 'pmc_write' + suffix, '*counter_collection.csv'))[0], 'WRITE_SIZE')
-        # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
-        out = collections.defaultdict(int)   # launches of one slot (the per-shape gradient launches of many-channel images) add up
-        for k in fetch:
-            out[slot(k)] += int(2 * fetch[k] * 1024 + write.get(k, 0) * 1024)
-        return dict(out)
-
-    traffic = traffic_of('')
-    path = os.path.join(dst, 'pmc_traffic.json')
-    allt = json.load(open(path)) if os.path.exists(path) else {}
-    allt[config] = traffic
-    allt['_collected'] = tag
-    if os.path.isdir(os.path.join(src, 'pmc_fetch_K5')):
-        allt['K5'] = traffic_of('_K5')
-        stats = os.path.join(src, 'trace_K5', 'trace_kernel_stats.csv')
+    for cfg in ('K5', 'K3-256'):
+        stats = os.path.join(src, 'trace_' + cfg, 'trace_kernel_stats.csv')
         if os.path.exists(stats):
-            shutil.copy(stats, os.path.join(dst, tag + '_kernel_stats_K5.csv'))
-    allt['_note'] = ('HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes); the factor 2 is the gfx950 FETCH_SIZE '
-                     'correction of MI355X_MICROARCH.md (calibrated there for wide coalesced reads; narrower accesses are uncalibrated)')
-    json.dump(allt, open(path, 'w'), indent=1)
-    # the bench lines were written before this summary existed: give them the traffic figures of this collection
-    for f in glob.glob(os.path.join(dst, tag + '_bench*.json')):
-        d = json.load(open(f))
-        cfg = d['config']['workload'].split(':')[0]
-        spg = d['config'].get('scenes_per_gpu', 1)
-        t = allt.get(cfg, {}).get(d['roofline']['kernel'])
-        d['roofline']['traffic'] = t * spg if t is not None else None
-        d['roofline']['traffic_source'] = ('profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of one scene of this workload%s, '
-                                           'not measured in the bench run' % (tag, ' x %d scenes per launch' % spg if spg > 1 else '')) if t is not None else None
-        json.dump(d, open(f, 'w'), indent=1)
-    print(json.dumps(traffic, indent=1))
+            shutil.copy(stats, os.path.join(dst, '%s_kernel_stats_%s.csv' % (tag, cfg)))
+    # HBM traffic per launch: written on the box by tools/measure_traffic.py, stamped with the kernel sources' sha256
+    # (bench.py uses an entry only when its stamp matches the tree; its default run measures the traffic itself)
+    t = os.path.join(src, 'pmc_traffic.json')
+    if os.path.exists(t):
+        shutil.copy(t, os.path.join(dst, 'pmc_traffic.json'))
+    for name in ('soak.log', 'traffic.log'):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, '%s_%s' % (tag, name.replace('.log', '.txt'))))
+    print(open(os.path.join(dst, tag + '_kernel_stats.csv')).read())
 
 
 if __name__ == '__main__':
