@@ -342,6 +342,18 @@ static inline void accumulate(double *acc, double *mass, size_t idx, float term,
     }
 }
 
+/* The CANCELLATION scale of a position-gradient term: the same product with every difference the reference forms on
+   the way -- the Scharr filter's (a + b) - c - d, sum_k b_k * vertex_k.x -- replaced by the sum of the magnitudes.  Where a
+   term is the rounding residue of such a difference (a frame one pixel wide: every tap of the x filter is the same
+   pixel, and ((a + b) - a) - b is +-ulp, not 0) its value is defined by the reference only up to a few ulps of THIS
+   scale -- nvcc's own choice of fma contraction would change it -- and so is the parity tolerance (tests/parity.py). */
+static inline void accumulate_cond(double *cond, size_t idx, double scale, int seq)
+{
+    if (!cond) return;
+    if (seq) cond[idx] += scale;
+    else atomic_add_d(&cond[idx], scale);
+}
+
 /*
  * assemble_grads for one scene and ONE channel group (csrc/rasterise_grad_egl.cu:93-236).
  * `pix` / `gpix` are the group's contiguous [B,H,W,G] slices (what TF hands the op after
@@ -351,6 +363,7 @@ static inline void accumulate(double *acc, double *mass, size_t idx, float term,
  */
 static void assemble_grads_group(double *grad_vertices /*[V,4]*/, double *grad_vertex_colors /*[V,C] */,
                                  double *mass_vertices /*[V,4] or NULL*/, double *mass_vertex_colors /*[V,C] or NULL*/,
+                                 double *cond_vertices /*[V,4] or NULL*/,
                                  float *grad_background /*[H,W,C] of this scene*/, float *debug_thingy /*[H,W,3] or NULL*/,
                                  const float *bary_w, const float *index_f, const float *pix, const float *gpix,
                                  const float *vertices /*[V,4] of this scene*/, int iib, int B, int H, int W, int G,
@@ -374,6 +387,7 @@ static void assemble_grads_group(double *grad_vertices /*[V,4]*/, double *grad_v
                flattened [B,H,W,1] tensor (quirk Q1); reads past the end are clamped to the last
                element here (undefined in the reference). */
             float sx[3], sy[3];
+            float asx[3], asy[3]; /* the filters' cancellation scale: the same taps, magnitudes summed */
             {
                 float t[3][3][3]; /* [oy+1][ox+1][ch] */
                 for (int oy = -1; oy <= 1; ++oy)
@@ -399,6 +413,9 @@ static void assemble_grads_group(double *grad_vertices /*[V,4]*/, double *grad_v
                     d2 = AT(0, -1, ch) - AT(0, +1, ch);
                     m1 = d1 * (3.f / 32.f); m2 = d2 * (10.f / 32.f);
                     sy[ch] = m1 + m2;
+                    float corners = (fabsf(AT(-1, -1, ch)) + fabsf(AT(-1, +1, ch))) + (fabsf(AT(+1, -1, ch)) + fabsf(AT(+1, +1, ch)));
+                    asx[ch] = corners * (3.f / 32.f) + (fabsf(AT(-1, 0, ch)) + fabsf(AT(+1, 0, ch))) * (10.f / 32.f);
+                    asy[ch] = corners * (3.f / 32.f) + (fabsf(AT(0, -1, ch)) + fabsf(AT(0, +1, ch))) * (10.f / 32.f);
                 }
 #undef AT
             }
@@ -467,20 +484,26 @@ static void assemble_grads_group(double *grad_vertices /*[V,4]*/, double *grad_v
             if (barycentric[0] != -1.f) {
                 const float width_f = (float)frame_width, height_f = (float)frame_height;
                 float dL_dx = 0.f, dL_dy = 0.f;
+                double c_dx = 0., c_dy = 0.; /* cancellation scales of dL_dx, dL_dy */
                 for (int channel = 0; channel < channels; ++channel) {
                     float dL_dchannel = g_here[channel];
                     float m = dL_dchannel * sx[channel];
                     dL_dx = dL_dx + m;
                     m = dL_dchannel * sy[channel];
                     dL_dy = dL_dy + m;
+                    c_dx += fabs((double)dL_dchannel) * asx[channel];
+                    c_dy += fabs((double)dL_dchannel) * asy[channel];
                 }
                 float clip_x = 0.f, clip_y = 0.f;
+                double c_clip_x = 0., c_clip_y = 0.;
                 for (int k = 0; k < 3; ++k) {
                     int vertex_index = (int)index_f3[k];
                     float m = barycentric[k] * vertices[(size_t)vertex_index * 4 + 0];
                     clip_x = clip_x + m;
+                    c_clip_x += fabs((double)m);
                     m = barycentric[k] * vertices[(size_t)vertex_index * 4 + 1];
                     clip_y = clip_y + m;
+                    c_clip_y += fabs((double)m);
                 }
                 for (int k = 0; k < 3; ++k) {
                     float d_xview_by_xclip = (.5f * width_f) / clip_w;
@@ -498,6 +521,13 @@ static void assemble_grads_group(double *grad_vertices /*[V,4]*/, double *grad_v
                     accumulate(grad_vertices, mass_vertices, (size_t)vertex_index * 4 + 0, gx, fabsf(gx), seq);
                     accumulate(grad_vertices, mass_vertices, (size_t)vertex_index * 4 + 1, gy, fabsf(gy), seq);
                     accumulate(grad_vertices, mass_vertices, (size_t)vertex_index * 4 + 3, gw, fabsf(gw1) + fabsf(gw2), seq);
+                    if (cond_vertices) {
+                        double bk = fabs((double)barycentric[k]), w1 = fabs((double)clip_w), w2 = w1 * w1;
+                        accumulate_cond(cond_vertices, (size_t)vertex_index * 4 + 0, c_dx * bk * (.5 * width_f) / w1, seq);
+                        accumulate_cond(cond_vertices, (size_t)vertex_index * 4 + 1, c_dy * bk * (.5 * height_f) / w1, seq);
+                        accumulate_cond(cond_vertices, (size_t)vertex_index * 4 + 3,
+                                        c_dx * bk * (.5 * width_f) * c_clip_x / w2 + c_dy * bk * (.5 * height_f) * c_clip_y / w2, seq);
+                    }
                 }
             }
         }
@@ -513,6 +543,7 @@ static void assemble_grads_group(double *grad_vertices /*[V,4]*/, double *grad_v
 int dirt_oracle_backward_ex(const float *vertices, const int32_t *faces, const float *pixels, const float *grad_pixels,
                             float *grad_background, float *grad_vertices, float *grad_vertex_colors, float *debug_thingy,
                             float *mass_vertices /*[B,V,4] or NULL*/, float *mass_vertex_colors /*[B,V,C] or NULL*/,
+                            float *cond_vertices /*[B,V,4] or NULL*/,
                             int B, int V, int F, int H, int W, int C, unsigned flags)
 {
     if (!check_dims(B, V, F, H, W, C)) return -1;
@@ -528,6 +559,7 @@ int dirt_oracle_backward_ex(const float *vertices, const int32_t *faces, const f
     double *gvc = (double *)calloc(nvc + 1, sizeof(double));
     double *mv = mass_vertices ? (double *)calloc(nv + 1, sizeof(double)) : NULL;
     double *mvc = mass_vertex_colors ? (double *)calloc(nvc + 1, sizeof(double)) : NULL;
+    double *cv = cond_vertices ? (double *)calloc(nv + 1, sizeof(double)) : NULL;
     float *bary_w = (float *)malloc(sizeof(float) * P * 4);
     float *index_f = (float *)malloc(sizeof(float) * P * 3);
     float *pix_g = (float *)malloc(sizeof(float) * (size_t)B * P * 3);
@@ -548,7 +580,7 @@ int dirt_oracle_backward_ex(const float *vertices, const int32_t *faces, const f
             scene_surfaces(of, F, H, W, bary_w, index_f);
             assemble_grads_group(gv_group + (size_t)ib * V * 4, gvc + (size_t)ib * V * C,
                                  mv ? mv + (size_t)ib * V * 4 : NULL, mvc ? mvc + (size_t)ib * V * C : NULL,
-                                 grad_background + (size_t)ib * P * C,
+                                 cv ? cv + (size_t)ib * V * 4 : NULL, grad_background + (size_t)ib * P * C,
                                  (debug_thingy && c_begin == 0) ? debug_thingy + (size_t)ib * P * 3 : NULL, bary_w, index_f,
                                  pix_g, gpix_g, verts, ib, B, H, W, G, C, c_begin, flags);
             free(of);
@@ -561,8 +593,9 @@ int dirt_oracle_backward_ex(const float *vertices, const int32_t *faces, const f
     for (size_t n = 0; n < nvc; ++n) grad_vertex_colors[n] = (float)gvc[n];
     if (mv) for (size_t n = 0; n < nv; ++n) mass_vertices[n] = (float)mv[n];
     if (mvc) for (size_t n = 0; n < nvc; ++n) mass_vertex_colors[n] = (float)mvc[n];
+    if (cv) for (size_t n = 0; n < nv; ++n) cond_vertices[n] = (float)cv[n];
     if (seq) free(gv_group);
-    free(gv); free(gvc); free(mv); free(mvc); free(bary_w); free(index_f); free(pix_g); free(gpix_g);
+    free(gv); free(gvc); free(mv); free(mvc); free(cv); free(bary_w); free(index_f); free(pix_g); free(gpix_g);
     return 0;
 }
 
@@ -571,7 +604,7 @@ int dirt_oracle_backward(const float *vertices, const int32_t *faces, const floa
                          int B, int V, int F, int H, int W, int C, unsigned flags)
 {
     return dirt_oracle_backward_ex(vertices, faces, pixels, grad_pixels, grad_background, grad_vertices, grad_vertex_colors,
-                                   debug_thingy, NULL, NULL, B, V, F, H, W, C, flags);
+                                   debug_thingy, NULL, NULL, NULL, B, V, F, H, W, C, flags);
 }
 
 /*

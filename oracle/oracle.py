@@ -42,7 +42,7 @@ def _load():
     lib.dirt_oracle_forward.restype = i
     lib.dirt_oracle_backward.argtypes = [fp, ip, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, ctypes.c_uint]
     lib.dirt_oracle_backward.restype = i
-    lib.dirt_oracle_backward_ex.argtypes = [fp, ip, fp, fp, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, ctypes.c_uint]
+    lib.dirt_oracle_backward_ex.argtypes = [fp, ip, fp, fp, fp, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, ctypes.c_uint]
     lib.dirt_oracle_backward_ex.restype = i
     lib.dirt_oracle_visibility.argtypes = [fp, ip, ip, fp, fp, i, i, i, i]
     lib.dirt_oracle_visibility.restype = i
@@ -96,7 +96,9 @@ def backward(vertices, faces, pixels, grad_pixels, flags=0, want_debug=False, wa
 
     `mass_*` is, per output element, the sum of |term| over everything the reference's atomics add into
     it (csrc/rasterise_grad_egl.cu:140,228-230; for `.w` the two products of :230 count separately): the
-    scale of the per-element tolerance |gpu - oracle| <= 1e-4 * mass of the parity tests."""
+    scale of the per-element tolerance |gpu - oracle| <= 1e-4 * mass of the parity tests.  `cond_vertices` is the
+    cancellation scale of the same terms (the Scharr differences and sum_k b_k * vertex_k taken with magnitudes): a term
+    that is the rounding residue of an exactly cancelling difference is defined only up to a few ulps of it."""
     lib = _load()
     vertices, faces, pixels, grad_pixels = _f(vertices), _i(faces), _f(pixels), _f(grad_pixels)
     B, H, W, C = pixels.shape
@@ -108,9 +110,10 @@ def backward(vertices, faces, pixels, grad_pixels, flags=0, want_debug=False, wa
     dbg = np.empty((B, H, W, 3), np.float32) if want_debug else None
     mv = np.empty((B, V, 4), np.float32) if want_mass else None
     mvc = np.empty((B, V, C), np.float32) if want_mass else None
+    cv = np.empty((B, V, 4), np.float32) if want_mass else None
     rc = lib.dirt_oracle_backward_ex(_fp(vertices), _ip(faces), _fp(pixels), _fp(grad_pixels), _fp(gb), _fp(gv), _fp(gvc),
                                      _fp(dbg) if want_debug else None, _fp(mv) if want_mass else None,
-                                     _fp(mvc) if want_mass else None, B, V, F, H, W, C, flags)
+                                     _fp(mvc) if want_mass else None, _fp(cv) if want_mass else None, B, V, F, H, W, C, flags)
     if rc != 0:
         raise ValueError('dirt_oracle_backward failed: %d' % rc)
     out = {'grad_background': gb, 'grad_vertices': gv, 'grad_vertex_colors': gvc}
@@ -119,6 +122,7 @@ def backward(vertices, faces, pixels, grad_pixels, flags=0, want_debug=False, wa
     if want_mass:
         out['mass_vertices'] = mv
         out['mass_vertex_colors'] = mvc
+        out['cond_vertices'] = cv
     return out
 
 

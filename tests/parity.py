@@ -6,13 +6,23 @@ output element is only defined up to the rounding of a sum; the scale of that ro
 the terms added into THAT element, which the oracle returns (`mass_vertices`, `mass_vertex_colors`:
 oracle/oracle.py::backward(want_mass=True)).  The check is per element:
 
-    |gpu - oracle| <= 1e-4 * mass[element]          (mass == 0  =>  gpu must be exactly 0)
+    |gpu - oracle| <= 1e-4 * mass[element] + 2^-20 * cond[element]
+
+`cond` (position gradients only; `cond_vertices`) is the CANCELLATION scale of the element's terms -- the same products
+with the Scharr filter's differences and sum_k b_k * vertex_k.x taken over magnitudes.  It matters where a term is the
+rounding residue of an exactly cancelling difference: in a frame one pixel wide every x tap is the same pixel and the
+reference's ((a + b) - a) - b is +-1 ulp of the taps, not 0; such an element's "mass" is 1e-10 of its neighbours' and
+its value is defined by the reference only up to a few ulps of the taps (nvcc's own fma contraction would change it).
+2^-20 is 16 float32 ulps of that scale (the residue of sum_k b_k * vertex_k.x alone carries the rounding of three
+barycentrics and three products: ~9 ulps observed); for ordinary elements cond is a small multiple of mass: at K3 the
+second term is 12 % of the first for the median element, 46 % at the 99th percentile.  Where both scales are 0 the GPU value must be exactly 0.
 
 Non-finite values (hostile geometry: clip_w underflow) must be non-finite on both sides in the same places.
 """
 import numpy as np
 
 GRAD_TOL = 1e-4
+COND_ULPS = 2.0 ** -20   # 16 float32 ulps of the cancellation scale
 KEYS = {'grad_vertices': 'mass_vertices', 'grad_vertex_colors': 'mass_vertex_colors'}
 
 
@@ -25,21 +35,22 @@ def _np(a):
 def grad_close(got, ow, key, what='', index=None, tol=GRAD_TOL):
     """`ow` is the oracle's backward dict (with masses), `key` one of KEYS; `index` selects a scene."""
     want, mass = ow[key], ow[KEYS[key]]
+    cond = ow['cond_vertices'] if key == 'grad_vertices' else np.zeros_like(mass)
     if index is not None:
-        want, mass = want[index], mass[index]
+        want, mass, cond = want[index], mass[index], cond[index]
     got = _np(got).astype(np.float64)
     assert got.shape == want.shape, '%s %s: shape %s vs %s' % (what, key, got.shape, want.shape)
-    bad_w = ~(np.isfinite(want) & np.isfinite(mass))
+    bad_w = ~(np.isfinite(want) & np.isfinite(mass) & np.isfinite(cond))
     bad_g = ~np.isfinite(got)
     assert np.array_equal(bad_w, bad_g), '%s %s: non-finite values in different places (%d oracle, %d gpu)' % (
         what, key, int(bad_w.sum()), int(bad_g.sum()))
     ok = ~bad_w
     err = np.abs(got - want.astype(np.float64))[ok]
-    lim = tol * mass.astype(np.float64)[ok]
+    lim = tol * mass.astype(np.float64)[ok] + COND_ULPS * cond.astype(np.float64)[ok]
     if err.size and not np.all(err <= lim):
         worst = int(np.argmax(err - lim))
-        raise AssertionError('%s %s: %d of %d elements outside %g * mass; worst err %g at mass %g (value %g)' % (
-            what, key, int(np.sum(err > lim)), err.size, tol, err[worst], lim[worst] / tol, want[ok][worst]))
+        raise AssertionError('%s %s: %d of %d elements outside %g * mass + 2^-20 * cond; worst err %g at mass %g, cond %g (value %g)' % (
+            what, key, int(np.sum(err > lim)), err.size, tol, err[worst], mass[ok][worst], cond[ok][worst], want[ok][worst]))
 
 
 def grads_close(got_vertices, got_vertex_colors, ow, what='', index=None, tol=GRAD_TOL):

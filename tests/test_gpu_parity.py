@@ -189,7 +189,7 @@ def test_reference_kernel_vectors_on_gpu(gpu):
         assert np.array_equal(gb.cpu().numpy(), ref[name + '/grad_background']), name
         assert np.array_equal(dbg.cpu().numpy(), ref[name + '/debug_thingy']), name
         want = {'grad_vertices': ref[name + '/grad_vertices'], 'grad_vertex_colors': ref[name + '/grad_vertex_colors'],
-                'mass_vertices': z['mass_vertices'], 'mass_vertex_colors': z['mass_vertex_colors']}
+                'mass_vertices': z['mass_vertices'], 'mass_vertex_colors': z['mass_vertex_colors'], 'cond_vertices': z['cond_vertices']}
         parity.grads_close(gv, gvc, want, name + ' vs reference kernel')
 
 

@@ -61,10 +61,10 @@ def _clip_jacobians(translation, rotation_xy):
 def _contract(ow, index, jac):
     """sum_v,k grad_vertices[v,k] * jac[v,k,...] with the per-element tolerance carried along."""
     g = ow['grad_vertices'][index].astype(np.float64)
-    m = ow['mass_vertices'][index].astype(np.float64)
+    m = parity.GRAD_TOL * ow['mass_vertices'][index].astype(np.float64) + parity.COND_ULPS * ow['cond_vertices'][index].astype(np.float64)
     extra = jac.ndim - 2
     gg, mm = g.reshape(g.shape + (1,) * extra), m.reshape(m.shape + (1,) * extra)
-    return (gg * jac).sum((0, 1)), parity.GRAD_TOL * (mm * np.abs(jac)).sum((0, 1))
+    return (gg * jac).sum((0, 1)), (mm * np.abs(jac)).sum((0, 1))
 
 
 def _assert_within(got, want, bound, what):
