@@ -341,6 +341,35 @@ def main():
                         'kind': 'port',
                         'sample': '%d x forward+backward of one %s scene (%dx%dx%d, %d triangles), oracle/dirt_oracle.c with OpenMP'
                                   % (n_it, args.config, H, W, C, F)}
+        # The one part of the reference that compiles for a CPU -- its gradient kernel assemble_grads + launch_grad_assembly,
+        # csrc/rasterise_grad_egl.cu, behind oracle/ref_shim (oracle/_ref, prebuilt: it travels with the snapshot) -- timed
+        # beside it: BACKWARD only (the channel groups of dirt/rasterise_ops.py:145-165, surfaces from the oracle's
+        # visibility, which is not timed), one thread by construction (the shim runs the CUDA grid as one thread).
+        try:
+            from oracle import ref as _ref
+            if _ref.available():
+                surf = _ref.surfaces(one['vertices'], one['faces'], H, W)
+                px1 = oracle.forward(one['background'], one['vertices'], one['vertex_colors'], one['faces'])
+
+                def ref_backward():
+                    begin = 0
+                    while begin < C:
+                        end = begin + 3 if begin + 3 <= C else begin + 1
+                        _ref.rasterise_grad_op(one['vertices'], one['faces'], px1[..., begin:end], one['grad_pixels'][..., begin:end], surf)
+                        begin = end
+                ref_backward()
+                n_r, t_r = 0, 0.0
+                while t_r < 3.0 and n_r < 50:
+                    c0 = time.perf_counter()
+                    ref_backward()
+                    t_r += time.perf_counter() - c0
+                    n_r += 1
+                cpu_baseline['reference_kernel_backward'] = {
+                    'value': n_r * P / t_r / 1e6, 'unit': 'Mpixels/s (backward only)', 'cores': 1, 'kind': 'reference',
+                    'sample': '%d x the reference\'s own assemble_grads (csrc/rasterise_grad_egl.cu compiled for the host, oracle/_ref) over '
+                              'the %d channel groups of one %s scene' % (n_r, (C // 3) + (C % 3), args.config)}
+        except Exception as e:  # the checker is optional here: never let it take the bench line down
+            cpu_baseline['reference_kernel_backward'] = {'error': str(e)[:120]}
 
     if rank == 0:
         step_bytes = algorithmic_bytes(P, V, F, C) * spg

@@ -22,6 +22,21 @@
 
 namespace dirt {
 
+#ifdef DIRT_TRACE
+// Per-wave phase timestamps for tools/trace_grad.py (the layout of dirt_grad.hip's trace); tracing build only.
+__device__ long long* g_trace_grad_small = nullptr;
+extern "C" void dirt_debug_set_trace_grad_small(void* p)
+{
+    long long* q = reinterpret_cast<long long*>(p);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_grad_small), &q, sizeof(q));
+}
+#define SMARK() do { if (tr_n < 12) { long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tr_t[tr_n++] = t_; } } while (0)
+#define SCOUNT(i, v) do { tr_c[i] += (v); } while (0)
+#else
+#define SMARK() do {} while (0)
+#define SCOUNT(i, v) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int ST = 16;            // tile side
@@ -62,6 +77,11 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
     __shared__ __align__(16) float2 s_inbox[4][SIB * SIB + 2];                   // per wave: (fx, fy) sent to each pixel of its region + ring
     constexpr int LC = CSPEC == 3 ? 4 : CSPEC;       // floats per staged pixel
 
+#ifdef DIRT_TRACE
+    long long tr_t[12]; int tr_n = 0; long long tr_c[4] = {0, 0, 0, 0};
+    const long long tr_wall0 = wall_clock64();
+#endif
+    SMARK();  // 0 start
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int iib = blockIdx.y;
     const int H = p.H, W = p.W;
@@ -146,7 +166,10 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
     }
     float bk[3];
     decode_bary(state_b[own], bk);
+    SMARK();  // 1 loads issued, tile stored
+    SMARK();  // 2
     __syncthreads();
+    SMARK();  // 3 barrier passed
 
     // ---- Scharr, the L1 norms that choose the dilation axis (:185, all three "channels" of the reference's Vec3 in its
     //      summation order) and dL/dx, dL/dy of :203-208, per channel group ----
@@ -203,12 +226,20 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
         }
     }
 
+    SMARK();  // 4 Scharr done
     // ---- the pixel and its four neighbours: clip_w and face ----
     const float2 s_own = s_vw[ly + 1][lx + 1], s_l = s_vw[ly + 1][lx], s_r = s_vw[ly + 1][lx + 2];
     const float2 s_u = s_vw[ly][lx + 1], s_d = s_vw[ly + 2][lx + 1];
     const float w_own = s_own.x;
     const int f_own = __float_as_int(s_own.y);
     const bool covered = in_px & (f_own >= 0);
+    // The vertex indices of this pixel's face, requested now: the face loop needs the indices of the face a row works on,
+    // and every face a row meets is the face of one of its lanes (or ring cells), so they are passed on by cross-lane
+    // maxima instead of a load per iteration -- a wave is about alone on its SIMD here, nothing would cover that round trip
+    // (per-wave trace at K3-256: 1727 clocks per iteration with the load, 7.3 iterations per wave).
+    struct Int3 { int32_t x, y, z; };
+    Int3 vid_own = {0, 0, 0};
+    if (p.F > 0) vid_own = *reinterpret_cast<const Int3*>(faces + (size_t)(covered ? f_own : 0) * 3);   // (F == 0: `faces` may be null)
 
     // ---- background gradient (:143-147): grad_pixels where nothing is covered, zero elsewhere ----
     if (in_px) {
@@ -258,12 +289,14 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
         }
     }
 
+    SMARK();  // 5 dilation done
     // ---- totals per target pixel: own + what the neighbours sent; the ring cells (targets outside this wave's region) ----
     const float2 in_own = inbox[my_cell];
     const float px_x = fx + in_own.x, px_y = fy + in_own.y;
     const float ndc_x = ((float)x + 0.5f) * p.two_over_w - 1.f, ndc_y = ((float)(H - 1 - y) + 0.5f) * p.two_over_h - 1.f;
     const float px_w = -(px_x * ndc_x + px_y * ndc_y);
     int lkey = -1;
+    Int3 lvid = {0, 0, 0};
     float lb[3] = {0.f, 0.f, 0.f}, lf[3] = {0.f, 0.f, 0.f};
     if (lane < SRING) {
         const int r = lane;
@@ -274,6 +307,7 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
             const int tly = 8 * (wave >> 1) + ty, tlx = 8 * (wave & 1) + tx;   // in the tile
             const int py = y0 + tly, pxx = x0 + tlx;
             lkey = __float_as_int(s_vw[tly + 1][tlx + 1].y);
+            lvid = *reinterpret_cast<const Int3*>(faces + (size_t)lkey * 3);
             decode_bary(state_b[(size_t)py * W + pxx], lb);
             const float nx = ((float)pxx + 0.5f) * p.two_over_w - 1.f, ny = ((float)(H - 1 - py) + 0.5f) * p.two_over_h - 1.f;
             lf[0] = v.x; lf[1] = v.y; lf[2] = -(v.x * nx + v.y * ny);
@@ -315,15 +349,33 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
         K = min(K, (uint32_t)__builtin_amdgcn_mov_dpp((int)K, 0x121 /* row_ror:1 */, 0xF, 0xF, true));
         return K;
     };
+    SCOUNT(0, __popcll(__builtin_amdgcn_ballot_w64(lkey >= 0)));
+    SMARK();  // 6 face loop starts
     uint32_t K = next_face();
     for (;;) {
         if (__builtin_amdgcn_ballot_w64(K != NONE) == 0ull) break;
+        SCOUNT(1, 1);
         const bool live = K != NONE;
-        const uint32_t fbase = (live ? K : 0u) * 12u;
+        const bool m0 = live & (pend0 == K), m1 = live & (pend1 == K);
+        // the face's three vertex indices, from whichever lanes of the row hold it (+1: 0 = "not mine"); all holders agree
+        uint32_t rvid[3];
+        {
+            const uint32_t h[3] = {m0 ? (uint32_t)vid_own.x + 1u : (m1 ? (uint32_t)lvid.x + 1u : 0u),
+                                   m0 ? (uint32_t)vid_own.y + 1u : (m1 ? (uint32_t)lvid.y + 1u : 0u),
+                                   m0 ? (uint32_t)vid_own.z + 1u : (m1 ? (uint32_t)lvid.z + 1u : 0u)};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                uint32_t r = h[k];
+                r = max(r, (uint32_t)__builtin_amdgcn_mov_dpp((int)r, 0x128 /* row_ror:8 */, 0xF, 0xF, true));
+                r = max(r, (uint32_t)__builtin_amdgcn_mov_dpp((int)r, 0x124 /* row_ror:4 */, 0xF, 0xF, true));
+                r = max(r, (uint32_t)__builtin_amdgcn_mov_dpp((int)r, 0x122 /* row_ror:2 */, 0xF, 0xF, true));
+                r = max(r, (uint32_t)__builtin_amdgcn_mov_dpp((int)r, 0x121 /* row_ror:1 */, 0xF, 0xF, true));
+                rvid[k] = r - 1u;   // (a row without a face this iteration: 0xFFFFFFFF, never used -- its totals are zero)
+            }
+        }
         int vsel[NROLES];
 #pragma unroll
-        for (int e = 0; e < NROLES; ++e) vsel[e] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(faces) + fbase + 4u * (uint32_t)role_k[e]);
-        const bool m0 = live & (pend0 == K), m1 = live & (pend1 == K);
+        for (int e = 0; e < NROLES; ++e) vsel[e] = (int)(role_k[e] == 0 ? rvid[0] : (role_k[e] == 1 ? rvid[1] : rvid[2]));
         pend0 = m0 ? NONE : pend0;
         pend1 = m1 ? NONE : pend1;
         float acc[NR];
@@ -356,6 +408,15 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
                 asm volatile("global_atomic_add_f32 %0, %1, off" : : "v"(dst[e]), "v"(total[e]) : "memory");
         K = K_next;
     }
+    SMARK();  // 7 done
+#ifdef DIRT_TRACE
+    if (lane == 0 && g_trace_grad_small) {
+        long long* o = g_trace_grad_small + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16;
+        for (int i = 0; i < 12; ++i) o[i] = i < tr_n ? tr_t[i] : 0;
+        o[12] = tr_c[0]; o[13] = tr_c[1];
+        o[14] = tr_wall0; o[15] = (((long long)wall_clock64() - tr_wall0) << 20) | (long long)(__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4 /* HW_REG_HW_ID */) & 0xFFFFF);
+    }
+#endif
 }
 
 hipError_t launch_grad_small(const GradParams& p, hipStream_t stream)

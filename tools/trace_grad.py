@@ -11,15 +11,17 @@ F, H, W, C, seed, rlo, rhi = scenes.CONFIGS[cfg]
 s = scenes.rand_scene(F, H, W, C, seed, rlo, rhi)
 dev = torch.device('cuda:0')
 t = {k: torch.from_numpy(np.ascontiguousarray(s[k]))[None].to(dev) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
-ntiles = ((W + 31) // 32) * ((H + 31) // 32)
+ntiles = max(((W + 31) // 32) * ((H + 31) // 32), ((W + 15) // 16) * ((H + 15) // 16))   # 16 x 16 tiles: the small-frame kernel
 buf = torch.zeros(ntiles * 4 * 16, dtype=torch.int64, device=dev)
 for it in range(3):
     px, state = ops._op_rasterise(t['background'], t['vertices'], t['vertex_colors'], t['faces'], H, W, C, keep_state=True)
     if it == 2:
         lib.dirt_debug_set_trace_grad(ctypes.c_void_p(buf.data_ptr()))
+        lib.dirt_debug_set_trace_grad_small(ctypes.c_void_p(buf.data_ptr()))
     ops._op_rasterise_grad(t['vertices'], t['faces'], px, t['grad_pixels'], H, W, C, state=state)
     torch.cuda.synchronize()
 a = buf.cpu().numpy().reshape(-1, 16)
+a = a[a[:, 0] != 0]   # (the buffer is sized for the larger of the two tilings)
 tt = a[:, :8].astype(np.float64)
 d = np.diff(tt, axis=1)
 names = ['issue loads + state tile', 'store planes', 'barrier', 'Scharr', 'dilation', 'list + roles', 'face loop']
