@@ -48,19 +48,38 @@ constexpr uint32_t Z24_CLEAR = 0x00FFFFFFu;  // glClear(GL_DEPTH_BUFFER_BIT) to 
 // Triangle set-up for one face (the GL primitive assembly + viewport transform).
 // Returns false when the face is dropped (bad index, non-finite data, zero area, behind the eye,
 // outside the depth range as a whole, or covering no pixel centre).
+// (In two steps so that a caller can put other work between the requests and their use: face_fetch_indices, then
+// face_fetch_vertices once the indices are there, then setup_face_from -- setup_kernel clears its buffers meanwhile.)
+__device__ __forceinline__ void face_fetch_indices(const int32_t* __restrict__ face, int32_t (&idx)[3])
+{
+    idx[0] = face[0]; idx[1] = face[1]; idx[2] = face[2];
+}
+// a bad index reads vertex 0 instead (the face is dropped by setup_face_from)
+__device__ __forceinline__ void face_fetch_vertices(const float* __restrict__ verts, int V, const int32_t (&idx)[3], float4 (&vv)[3])
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        vv[k] = V > 0 ? *reinterpret_cast<const float4*>(verts + (size_t)((uint32_t)idx[k] < (uint32_t)V ? idx[k] : 0) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ inline bool setup_face_from(const float4 (&vv)[3], const int32_t (&idx)[3], int V, int H, int W, FaceRec& rec, FaceBox& box);
+
 __device__ inline bool setup_face(const float* __restrict__ verts, int V, const int32_t* __restrict__ face,
                                   int H, int W, FaceRec& rec, FaceBox& box)
 {
+    // the three indices, then the three vertices, are requested together (two memory latencies, not six)
+    int32_t idx[3];
+    float4 vv[3];
+    face_fetch_indices(face, idx);
+    face_fetch_vertices(verts, V, idx, vv);
+    return setup_face_from(vv, idx, V, H, W, rec, box);
+}
+
+__device__ inline bool setup_face_from(const float4 (&vv)[3], const int32_t (&idx)[3], int V, int H, int W, FaceRec& rec, FaceBox& box)
+{
     double X[3], Y[3], Wc[3], Z[3];
-    // the three indices, then the three vertices, are requested together (two memory latencies, not six); a bad
-    // index reads vertex 0 instead and drops the face afterwards
-    const int32_t i0 = face[0], i1 = face[1], i2 = face[2];
+    const int32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
     const bool index_ok = ((uint32_t)i0 < (uint32_t)V) & ((uint32_t)i1 < (uint32_t)V) & ((uint32_t)i2 < (uint32_t)V);
     if (V <= 0) return false;
-    float4 vv[3];
-    vv[0] = *reinterpret_cast<const float4*>(verts + (size_t)((uint32_t)i0 < (uint32_t)V ? i0 : 0) * 4);
-    vv[1] = *reinterpret_cast<const float4*>(verts + (size_t)((uint32_t)i1 < (uint32_t)V ? i1 : 0) * 4);
-    vv[2] = *reinterpret_cast<const float4*>(verts + (size_t)((uint32_t)i2 < (uint32_t)V ? i2 : 0) * 4);
     if (!index_ok) return false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

@@ -30,6 +30,15 @@ namespace dirt {
 
 #ifdef DIRT_TRACE
 __device__ long long* g_trace_buf = nullptr;
+__device__ long long* g_trace_setup = nullptr;
+extern "C" void dirt_debug_set_trace_setup(void* p)
+{
+    long long* q = reinterpret_cast<long long*>(p);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_setup), &q, sizeof(q));
+}
+#define SETUP_MARK() do { if (st_n < 8) { long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_t[st_n++] = t_; } } while (0)
+#else
+#define SETUP_MARK() do {} while (0)
 #endif
 
 // ---- binning ---------------------------------------------------------------------------------
@@ -72,6 +81,23 @@ __global__ __launch_bounds__(STHREADS * NW) void setup_kernel(GeomParams g)
     __shared__ uint32_t s_cnt[MAX_BINS + 1];    // [MAX_BINS] = big faces
     __shared__ uint32_t s_start[MAX_BINS + 1];  // exclusive prefix of s_cnt = the chunk's segment layout
     const int ib = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x & 63, tid = threadIdx.x;
+#ifdef DIRT_TRACE
+    long long st_t[8]; int st_n = 0;
+    const long long st_wall0 = wall_clock64();
+#endif
+    SETUP_MARK();  // 0 start
+    static_assert(MAX_BINS == 4 * STHREADS, "four bins per lane");
+    const int f0 = chunk * g.chunk_faces, f1 = min(g.F, f0 + g.chunk_faces);
+    const float* __restrict__ verts = g.vertices + (size_t)ib * g.V * 4;
+    // This thread's first face: its indices, then its vertices, are requested before anything else, and the clearing
+    // below runs while they are on their way (a chunk is one wave, alone on its SIMD: per-wave trace 1900 clocks of
+    // clearing followed by two exposed round trips, before this order).
+    const bool have_first = f0 + tid < f1;
+    int32_t idx_first[3] = {0, 0, 0};
+    float4 vv_first[3];
+    if (have_first) face_fetch_indices(g.faces + (g.shared_faces ? (size_t)(f0 + tid) : (size_t)ib * g.F + f0 + tid) * 3, idx_first);
+    for (int i = tid; i <= MAX_BINS; i += NT) s_cnt[i] = 0;
+    if (have_first) face_fetch_vertices(verts, g.V, idx_first, vv_first);
     // side job: clear the gradient accumulators of the backward pass (the cudaMemsetAsync x4 of
     // csrc/rasterise_grad_egl.cu:244-250) so that no separate launch is needed for it
     {
@@ -89,11 +115,8 @@ __global__ __launch_bounds__(STHREADS * NW) void setup_kernel(GeomParams g)
         if (gtid < (g.zero_b_bytes % 16) / 4) tb[gtid] = 0u;
         if (gtid < (g.zero_c_bytes % 16) / 4) tc[gtid] = 0u;
     }
-    static_assert(MAX_BINS == 4 * STHREADS, "four bins per lane");
-    for (int i = tid; i <= MAX_BINS; i += NT) s_cnt[i] = 0;
     __syncthreads();
-    const int f0 = chunk * g.chunk_faces, f1 = min(g.F, f0 + g.chunk_faces);
-    const float* __restrict__ verts = g.vertices + (size_t)ib * g.V * 4;
+    SETUP_MARK();  // 1 cleared, first face requested
 
     // ---- pass 1: set-up + histogram ----
     FaceBox first_box;  // the box of this thread's first face stays in registers for pass 2
@@ -102,7 +125,9 @@ __global__ __launch_bounds__(STHREADS * NW) void setup_kernel(GeomParams g)
         const size_t n = (size_t)ib * g.F + f;
         FaceRec rec;
         FaceBox box;
-        if (setup_face(verts, g.V, g.faces + (g.shared_faces ? (size_t)f : n) * 3, g.H, g.W, rec, box)) {
+        const bool ok = (f == f0 + tid) ? setup_face_from(vv_first, idx_first, g.V, g.H, g.W, rec, box)
+                                        : setup_face(verts, g.V, g.faces + (g.shared_faces ? (size_t)f : n) * 3, g.H, g.W, rec, box);
+        if (ok) {
             g.recs[n] = rec;
             int bx0, bx1, by0, by1;
             if (bin_range(box, g.grid, bx0, bx1, by0, by1)) {
@@ -118,19 +143,24 @@ __global__ __launch_bounds__(STHREADS * NW) void setup_kernel(GeomParams g)
         if (f == f0 + tid) first_box = box;
         if (g.chunk_faces > NT) g.boxes[n] = box;  // re-read in pass 2 when a thread owns several faces
     }
+    SETUP_MARK();  // 2 pass 1 done (set-up + histogram)
     __syncthreads();
+    SETUP_MARK();  // 3
 
     // ---- the chunk's segment layout: exclusive prefix over the 257 (pseudo-)bins, four bins per lane of the first wave ----
     if (tid < STHREADS) {
         uint32_t cnt[4], sum = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { cnt[i] = s_cnt[4 * lane + i]; sum += cnt[i]; }
+        // inclusive prefix over the 64 lanes: four DPP row shifts inside each row of 16, then the rows' totals carried
+        // across with row_bcast:15 / row_bcast:31 (six ds_bpermute shuffles before: an LDS round trip each)
         uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112 /* row_shr:2 */, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114 /* row_shr:4 */, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118 /* row_shr:8 */, 0xF, 0xF, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);   // rows 1, 3 += last lane of rows 0, 2
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);   // rows 2, 3 += last lane of row 1
         uint32_t start = incl - sum;
         // the directory is stored bin-major, [bin][chunk]: what a raster tile reads -- its bin's cell of every chunk -- is
         // then contiguous (nchunk x 8 bytes = a few lines, instead of one line per chunk)
@@ -149,6 +179,7 @@ __global__ __launch_bounds__(STHREADS * NW) void setup_kernel(GeomParams g)
     __syncthreads();
     for (int i = tid; i <= MAX_BINS; i += NT) s_cnt[i] = 0;  // reused as the fill cursors
     __syncthreads();
+    SETUP_MARK();  // 4 prefix + directory done
 
     // ---- pass 2: faces claim their slots in the chunk's segment ----
     BinEntry* __restrict__ out = g.entries + ((size_t)ib * g.nchunk + chunk) * (5 * (size_t)g.chunk_faces);
@@ -168,6 +199,14 @@ __global__ __launch_bounds__(STHREADS * NW) void setup_kernel(GeomParams g)
             out[s_start[MAX_BINS] + atomicAdd(&s_cnt[MAX_BINS], 1u)] = e;
         }
     }
+    SETUP_MARK();  // 5 pass 2 done
+#ifdef DIRT_TRACE
+    if (lane == 0 && g_trace_setup) {
+        long long* o = g_trace_setup + ((size_t)blockIdx.x * NW + (tid >> 6)) * 16;
+        for (int i = 0; i < 8; ++i) o[i] = i < st_n ? st_t[i] : 0;
+        o[8] = st_wall0; o[9] = (long long)wall_clock64() - st_wall0;
+    }
+#endif
 }
 
 // A tile is 2 x 2 wave regions; a wave region is NB x NB blocks of 8 x 8 pixels (NB * NB pixels per lane).
