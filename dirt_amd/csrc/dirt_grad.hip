@@ -771,18 +771,26 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
         else                                                                                                    \
             hipLaunchKernelGGL((grad_kernel<SHAPE_, STRIDED_, false>), grid, block, dyn_lds, stream, p);        \
     } while (0)
-    // Small frames (at most one 32 x 32 tile per compute unit): the one-pixel-per-lane kernel on 16 x 16 tiles
-    // (dirt_grad_small.hip) -- four times the waves, a handful of faces per 4 x 4 block instead of ~18 per region.
-    // Channel counts without a specialised instance of it (many-channel G-buffers) keep the strided passes below.
+    // Which shape (measured on MI355X, gradient kernel in us; faces per 32 x 32 tile = F / tiles):
+    //                       tiles  faces/tile   px1    rows   pairs
+    //   K3-256  (10k faces)    64     156       10.6   20.7   26.1
+    //   K3-384                144      69       18.1   18.1   19.9
+    //   K3-512                256      39       22.5   18.7   18.4
+    //   K3-768                576      17       39.8   25.8   22.9
+    //   12 large faces, 256^2  64     0.2       27.7   14.4   10.6
+    // The one-pixel-per-lane kernel (dirt_grad_small.hip: four times the waves, a handful of faces per 4 x 4 block) pays
+    // where a small frame is DENSE in faces; with few large faces its per-block atomics all land on the same vertices.
+    // Every row its own face (more atomics, fewer iterations) pays for moderately dense small frames; pairs otherwise.
+    const long long density = ntiles ? (long long)p.F / (long long)ntiles : 0;   // faces per 32 x 32 tile
+    const bool few_tiles = (long long)ntiles * p.B <= 256;                       // at most one workgroup per compute unit
     {
-        const bool small_ok = p.C == 1 || p.C == 3 || p.C == 4;
-        bool small = small_ok && (long long)ntiles * p.B <= 256;
+        const bool small_ok = p.C == 1 || p.C == 3 || p.C == 4;   // (many-channel G-buffers keep the strided passes below)
+        bool small = small_ok && few_tiles && density >= 96;
         if (p.flags & DIRT_FLAG_GRAD_SMALL) small = small_ok;
         if (p.flags & (DIRT_FLAG_GRAD_ROWS | DIRT_FLAG_GRAD_PAIRS)) small = false;
         if (small) return launch_grad_small(p, stream);
     }
-    // every row its own face where the frame is small: at most one workgroup per CU, the float atomics have room
-    bool rows = (long long)ntiles * p.B <= 256;
+    bool rows = few_tiles && density >= 48;
     if (p.flags & DIRT_FLAG_GRAD_ROWS) rows = true;
     if (p.flags & DIRT_FLAG_GRAD_PAIRS) rows = false;
     p.c_first = 0; p.npasses = 1;
