@@ -100,6 +100,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)')
+    # DIRT_BENCH_SHARE_GPU=1: every rank uses GPU 0 and the process group runs over gloo -- ONLY to exercise the N > 1
+    # control flow (barriers, max-over-ranks timing, scaling_reference) on a one-GPU box; RCCL refuses two ranks on one
+    # device.  The line it prints says so (`config.parallelism`).
+    share_gpu = os.environ.get('DIRT_BENCH_SHARE_GPU') == '1'
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     distributed = world > 1
@@ -107,7 +113,10 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=dev)
+        if share_gpu:
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=dev)
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)            # proof that RCCL sees every rank; outside the timed region
         ranks_seen = int(ones.item())
@@ -381,7 +390,7 @@ def main():
             'dtype': 'f32 (f64 edge functions)', 'data': 'synthetic',
             'config': {'workload': '%s: rand_mesh F=%d at %dx%dx%d, %d scene(s) per GPU, forward+backward'
                                    % (args.config, F, H, W, C, spg),
-                       'scenes_per_gpu': spg, 'parallelism': 'batch-sharded x%d, no collective' % world,
+                       'scenes_per_gpu': spg, 'parallelism': 'batch-sharded x%d, no collective' % world + (' (DIRT_BENCH_SHARE_GPU: all ranks on ONE GPU over gloo, control-flow test only)' if share_gpu else ''),
                        'launch': 'one captured hipGraph replayed per step' if use_graph else 'eager (Python wrapper + C ABI per step)'},
             'ranks_seen': ranks_seen,
             'ms_per_step_eager': calib['eager_ms_per_step'], 'ms_per_step_graph': calib['graph_ms_per_step'],
