@@ -19,10 +19,13 @@
  * is closed source, un-vendored and cannot run here.  The forward restatement therefore follows
  * the OpenGL 3.3 core specification (sections 2.13, 2.14, 3.6, 4.1.5) and is pinned by the only
  * known-answer test the reference has, tests/square_test.py:11-17,54-57 (see tests/test_oracle.py).
- * The reference has NO gradient test of any kind: the backward restatement follows the CUDA source
- * line by line and is pinned by invariants that follow from that source plus finite differences
- * for the exact (colour / background) derivatives.  "parity unpinned" applies to everything the
- * square test does not exercise (y orientation, perspective, depth ordering, C=3, gradients).
+ * The reference has NO gradient test of any kind, but its gradient kernel compiles for the host:
+ * oracle/_ref (oracle/make_ref.py) is csrc/rasterise_grad_egl.cu itself behind a TensorFlow / CUDA shim,
+ * and with DIRT_ORACLE_FLAG_F32_SEQUENTIAL the backward restatement below equals it BIT FOR BIT in all
+ * four outputs (tests/test_oracle_ref.py; committed vectors tests/golden/ref_grads.npz), given the
+ * visibility surfaces.  "parity unpinned" therefore applies to the FORWARD / visibility arithmetic
+ * beyond the square test (y orientation, perspective, depth ordering, C=3): pinned to the GL
+ * specification, not to a reference run.
  *
  * NUMERIC SPECIFICATION (shared, by specification and not by code, with the HIP kernels; see
  * DESIGN.md section "Numeric specification").  Every operation below is an IEEE-754 basic
