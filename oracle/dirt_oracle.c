@@ -23,9 +23,12 @@
  * oracle/_ref (oracle/make_ref.py) is csrc/rasterise_grad_egl.cu itself behind a TensorFlow / CUDA shim,
  * and with DIRT_ORACLE_FLAG_F32_SEQUENTIAL the backward restatement below equals it BIT FOR BIT in all
  * four outputs (tests/test_oracle_ref.py; committed vectors tests/golden/ref_grads.npz), given the
- * visibility surfaces.  "parity unpinned" therefore applies to the FORWARD / visibility arithmetic
- * beyond the square test (y orientation, perspective, depth ordering, C=3): pinned to the GL
- * specification, not to a reference run.
+ * visibility surfaces; and the forward restatement equals the reference's own upload_background /
+ * download_pixels (csrc/rasterise_egl.cu, same shim) around dirt_oracle_draw_gl, a draw that knows only GL
+ * window coordinates: vertical flip, atlas tiling and channel packing are the reference's.  "parity
+ * unpinned" therefore applies to what the GL driver does in between -- coverage, perspective-correct
+ * interpolation, depth ordering beyond the square test: pinned to the GL specification, not to a
+ * reference run.
  *
  * NUMERIC SPECIFICATION (shared, by specification and not by code, with the HIP kernels; see
  * DESIGN.md section "Numeric specification").  Every operation below is an IEEE-754 basic
@@ -608,6 +611,52 @@ int dirt_oracle_backward(const float *vertices, const int32_t *faces, const floa
 {
     return dirt_oracle_backward_ex(vertices, faces, pixels, grad_pixels, grad_background, grad_vertices, grad_vertex_colors,
                                    debug_thingy, NULL, NULL, NULL, B, V, F, H, W, C, flags);
+}
+
+/*
+ * Test helper: the GL draw of ONE scene in the framebuffer's OWN frame (csrc/rasterise_egl.cpp:362-380 with the
+ * pass-through shaders csrc/shaders.cpp:16-43): RGBA32F atlas [atlas_h][atlas_w][4], row 0 = the bottom row, viewport
+ * (frame_x, frame_y, W, H); a depth buffer cleared to 1.0 for the call; faces in index order, GL_LESS; the fragment
+ * shader writes vec4(colour, 1) with a 1-channel attribute's missing components 0 (csrc/rasterise_egl.cpp:208).
+ * Nothing here knows about tensor rows: every sample is addressed by its window coordinates (i + 0.5, j + 0.5), and no
+ * bounding box is used.  oracle/ref.py puts the reference's own upload_background / download_pixels around it
+ * (csrc/rasterise_egl.cu, compiled for the host) and tests/test_oracle_ref.py requires the result to equal
+ * dirt_oracle_forward bit for bit: that pins the vertical flip and the atlas tiling of the forward restatement to the
+ * reference's code.  C in {1, 3}.
+ */
+int dirt_oracle_draw_gl(const float *vertices, const float *vertex_colors, const int32_t *faces, float *atlas,
+                        int V, int F, int H, int W, int C, int atlas_w, int atlas_h, int frame_x, int frame_y)
+{
+    if (!check_dims(1, V, F, H, W, C) || (C != 1 && C != 3)) return -1;
+    if (frame_x < 0 || frame_y < 0 || frame_x + W > atlas_w || frame_y + H > atlas_h) return -2;
+    OFace *of = setup_scene(vertices, V, faces, F, H, W);
+    uint32_t *zbuf = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)H * W);
+    for (size_t n = 0; n < (size_t)H * W; ++n) zbuf[n] = 0x00FFFFFFu; /* glClear(GL_DEPTH_BUFFER_BIT) */
+    for (int f = 0; f < F; ++f) {
+        const OFace *o = &of[f];
+        if (!o->valid) continue;
+        const float *c0 = vertex_colors + (size_t)o->vid[0] * C, *c1 = vertex_colors + (size_t)o->vid[1] * C,
+                    *c2 = vertex_colors + (size_t)o->vid[2] * C;
+        for (int j = 0; j < H; ++j)       /* GL window row, bottom first */
+            for (int i = 0; i < W; ++i) { /* GL window column */
+                double E[3];
+                uint32_t z24;
+                double px = (double)i + 0.5, py = (double)j + 0.5;
+                if (!sample_inside(o, px, py, E)) continue;
+                if (!sample_depth(o, px, py, &z24)) continue;
+                uint32_t *zb = &zbuf[(size_t)j * W + i];
+                if (!(z24 < *zb)) continue;
+                *zb = z24;
+                float b[3], cw;
+                sample_bary(o, E, b, &cw);
+                float *texel = atlas + (((size_t)(frame_y + j)) * atlas_w + (frame_x + i)) * 4;
+                for (int c = 0; c < 3; ++c) texel[c] = c < C ? fmaf(b[2], c2[c], fmaf(b[1], c1[c], b[0] * c0[c])) : 0.f;
+                texel[3] = 1.f;
+            }
+    }
+    free(zbuf);
+    free(of);
+    return 0;
 }
 
 /*

@@ -46,6 +46,8 @@ def _load():
     lib.dirt_oracle_backward_ex.restype = i
     lib.dirt_oracle_visibility.argtypes = [fp, ip, ip, fp, fp, i, i, i, i]
     lib.dirt_oracle_visibility.restype = i
+    lib.dirt_oracle_draw_gl.argtypes = [fp, fp, ip, fp, i, i, i, i, i, i, i, i, i]
+    lib.dirt_oracle_draw_gl.restype = i
     lib.dirt_oracle_num_threads.restype = i
     lib.dirt_oracle_set_num_threads.argtypes = [i]
     _lib = lib
@@ -138,6 +140,18 @@ def visibility(vertices, faces, height, width):
     if rc != 0:
         raise ValueError('dirt_oracle_visibility failed: %d' % rc)
     return fid, bary, cw
+
+
+def draw_gl(vertices, vertex_colors, faces, atlas, height, width, frame_x, frame_y):
+    """The GL draw of one scene into `atlas` [atlas_h, atlas_w, 4] (float32, GL orientation, modified in place) with the
+    viewport (frame_x, frame_y, width, height); no notion of tensor rows (see dirt_oracle_draw_gl)."""
+    lib = _load()
+    vertices, vertex_colors, faces = _f(vertices), _f(vertex_colors), _i(faces)
+    assert atlas.dtype == np.float32 and atlas.flags['C_CONTIGUOUS'] and atlas.ndim == 3 and atlas.shape[2] == 4
+    rc = lib.dirt_oracle_draw_gl(_fp(vertices), _fp(vertex_colors), _ip(faces), _fp(atlas), vertices.shape[0], faces.shape[0],
+                                 height, width, vertex_colors.shape[1], atlas.shape[1], atlas.shape[0], frame_x, frame_y)
+    if rc != 0:
+        raise ValueError('dirt_oracle_draw_gl failed: %d' % rc)
 
 
 # Names of the reference's op module (dirt/rasterise_ops.py:81,113)

@@ -39,6 +39,10 @@ def _load():
         lib.dirt_ref_rasterise_grad.restype = i
         lib.dirt_ref_upload_vertices.argtypes = [fp, ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p, i, i, i]
         lib.dirt_ref_upload_vertices.restype = i
+        lib.dirt_ref_upload_background.argtypes = [fp, fp] + [i] * 6
+        lib.dirt_ref_upload_background.restype = i
+        lib.dirt_ref_download_pixels.argtypes = [fp, fp] + [i] * 6
+        lib.dirt_ref_download_pixels.restype = i
         _lib = lib
     return _lib
 
@@ -134,6 +138,49 @@ def backward(vertices, faces, pixels, grad_pixels):
             'grad_vertex_colors': np.concatenate([r['grad_vertex_colors'] for r in results], -1),
             'grad_background': np.concatenate([r['grad_background'] for r in results], -1),
             'debug_thingy': results[0]['debug_thingy']}
+
+
+def rasterise_op(background, vertices, vertex_colors, faces):
+    """One `Rasterise` op call, channels in {1, 3}, as RasteriseOpGpu::Compute runs it (csrc/rasterise_egl.cpp:276-407):
+    the reference's OWN upload_background (background -> framebuffer atlas: vertical flip, scene tiling, C = 1 replicated),
+    a GL draw per scene with the viewport of :362-369, the reference's OWN download_pixels.  The draw itself is the
+    oracle's flip-free `draw_gl`: the GL pipeline is the one part of the op that is not the reference's source."""
+    lib = _load()
+    background = np.ascontiguousarray(background, np.float32)
+    vertices = np.ascontiguousarray(vertices, np.float32)
+    vertex_colors = np.ascontiguousarray(vertex_colors, np.float32)
+    faces = np.ascontiguousarray(faces, np.int32)
+    B, H, W, C = background.shape
+    assert C in (1, 3)
+    bh, bw = atlas_shape(B, H, W)   # the forward op sizes its atlas the same way (csrc/rasterise_egl.cpp:326-334)
+    atlas = np.full((bh, bw, 4), np.nan, np.float32)
+    rc = lib.dirt_ref_upload_background(_fp(background), _fp(atlas), B, H, W, C, bw, bh)
+    if rc != 0:
+        raise ValueError('dirt_ref_upload_background failed: %d' % rc)
+    frames_per_row = bw // W
+    for ib in range(B):
+        _oracle.draw_gl(vertices[ib], vertex_colors[ib], faces[ib], atlas, H, W, (ib % frames_per_row) * W, (ib // frames_per_row) * H)
+    pixels = np.full((B, H, W, C), np.nan, np.float32)
+    rc = lib.dirt_ref_download_pixels(_fp(atlas), _fp(pixels), B, H, W, C, bw, bh)
+    if rc != 0:
+        raise ValueError('dirt_ref_download_pixels failed: %d' % rc)
+    return pixels
+
+
+def forward(background, vertices, vertex_colors, faces):
+    """`rasterise_batch`'s channel grouping, dirt/rasterise_ops.py:86-108: one op for 1 or 3 channels, else groups of three
+    while three remain, then singles, concatenated."""
+    background = np.asarray(background, np.float32)
+    vertex_colors = np.asarray(vertex_colors, np.float32)
+    channels = background.shape[3]
+    if channels in (1, 3):
+        return rasterise_op(background, vertices, vertex_colors, faces)
+    pixels, begin_channel = [], 0
+    while begin_channel < channels:
+        end_channel = begin_channel + 3 if begin_channel + 3 <= channels else begin_channel + 1
+        pixels.append(rasterise_op(background[..., begin_channel:end_channel], vertices, vertex_colors[..., begin_channel:end_channel], faces))
+        begin_channel = end_channel
+    return np.concatenate(pixels, -1)
 
 
 def upload_vertices(vertices, faces):

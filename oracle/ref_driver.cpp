@@ -1,9 +1,10 @@
 /*
- * C entry points around the reference's own launch_grad_assembly / launch_vertex_upload
+ * C entry points around the reference's own launch_grad_assembly / launch_vertex_upload /
+ * launch_background_upload / launch_pixels_download
  * (TEST INFRASTRUCTURE; built only into oracle/_ref/, see oracle/make_ref.py).
  *
- * The reference translation unit (/root/reference/csrc/rasterise_grad_egl.cu, compiled for the host
- * through oracle/ref_shim/) supplies every line of arithmetic; this file only wraps caller-owned
+ * The reference translation units (/root/reference/csrc/rasterise_grad_egl.cu and csrc/rasterise_egl.cu,
+ * compiled for the host through oracle/ref_shim/) supply every line of arithmetic and indexing; this file only wraps caller-owned
  * numpy buffers into the shim's tensorflow::Tensor and calls it the way
  * RasteriseGradOpGpu::Compute does (csrc/rasterise_grad_egl.cpp:380-391,464-472).
  */
@@ -11,6 +12,13 @@
 #include "rasterise_grad_common.h"
 
 thread_local dim3 blockIdx, blockDim, threadIdx, gridDim;
+
+// csrc/rasterise_egl.cu has no header of its own: its two launchers are declared where they are used
+// (csrc/rasterise_egl.cpp:24-25)
+void launch_background_upload(cudaArray_t &dest_array, tensorflow::Tensor const &src_tensor, int const dest_height, int const dest_width,
+                              Eigen::GpuDevice const &device);
+void launch_pixels_download(tensorflow::Tensor &dest_tensor, cudaArray_t const &src_array, int const src_height, int const src_width,
+                            Eigen::GpuDevice const &device);
 
 extern "C" {
 
@@ -38,12 +46,39 @@ int dirt_ref_rasterise_grad(const float *vertices, const float *pixels, const fl
     Tensor pixels_tensor(const_cast<float *>(pixels), {B, H, W, C});
     Tensor grad_pixels_tensor(const_cast<float *>(grad_pixels), {B, H, W, C});
     Tensor vertices_tensor(const_cast<float *>(vertices), {B, V, 4});
-    RefShimArray const barycentrics_and_depth_array{reinterpret_cast<float4 const *>(barycentrics_and_depth), buffer_width, buffer_height};
-    RefShimArray const indices_array{reinterpret_cast<float4 const *>(indices), buffer_width, buffer_height};
+    RefShimArray const barycentrics_and_depth_array{reinterpret_cast<float4 *>(const_cast<float *>(barycentrics_and_depth)), buffer_width, buffer_height};
+    RefShimArray const indices_array{reinterpret_cast<float4 *>(const_cast<float *>(indices)), buffer_width, buffer_height};
     Eigen::GpuDevice device;
     launch_grad_assembly(grad_vertices_tensor, grad_vertex_colors_tensor, grad_background_tensor, debug_thingy_tensor,
                          &barycentrics_and_depth_array, &indices_array,
                          pixels_tensor, grad_pixels_tensor, vertices_tensor, buffer_width, buffer_height, device);
+    return 0;
+}
+
+/*
+ * The forward op's two data movers (csrc/rasterise_egl.cpp:348-356,386-392): background [B,H,W,C] -> the RGBA32F
+ * framebuffer atlas [buffer_height, buffer_width] float4 (GL orientation, scenes tiled), and back into pixels [B,H,W,C];
+ * C in {1, 3}.  What happens in between -- the GL draw -- is not the reference's code (oracle.draw_gl stands in for it).
+ */
+int dirt_ref_upload_background(const float *background, float *atlas, int B, int H, int W, int C, int buffer_width, int buffer_height)
+{
+    if (B < 1 || H < 1 || W < 1 || (C != 1 && C != 3) || buffer_width % W || buffer_height % H) return -1;
+    tensorflow::Tensor src(const_cast<float *>(background), {B, H, W, C});
+    RefShimArray const array{reinterpret_cast<float4 *>(atlas), buffer_width, buffer_height};
+    cudaArray_t handle = &array;
+    Eigen::GpuDevice device;
+    launch_background_upload(handle, src, buffer_height, buffer_width, device);
+    return 0;
+}
+
+int dirt_ref_download_pixels(const float *atlas, float *pixels, int B, int H, int W, int C, int buffer_width, int buffer_height)
+{
+    if (B < 1 || H < 1 || W < 1 || (C != 1 && C != 3) || buffer_width % W || buffer_height % H) return -1;
+    tensorflow::Tensor dest(pixels, {B, H, W, C});
+    RefShimArray const array{reinterpret_cast<float4 *>(const_cast<float *>(atlas)), buffer_width, buffer_height};
+    cudaArray_t const handle = &array;
+    Eigen::GpuDevice device;
+    launch_pixels_download(dest, handle, buffer_height, buffer_width, device);
     return 0;
 }
 

@@ -4,16 +4,17 @@
  * /root/reference/csrc/rasterise_grad_egl.cu includes <tensorflow/core/framework/tensor.h> and is
  * written in CUDA.  Neither TensorFlow nor CUDA exists in this image, so oracle/make_ref.py puts this
  * directory on the include path: this header supplies just enough of both vocabularies for the
- * reference translation unit (Vec3, assemble_grads, launch_grad_assembly, upload_vertices,
- * launch_vertex_upload: csrc/rasterise_grad_egl.cu:11-278) to compile unmodified with g++ and to run
- * as one sequential "thread" on the host.  Nothing here restates the reference's algorithm; it only
+ * reference's two CUDA translation units -- csrc/rasterise_grad_egl.cu (Vec3, assemble_grads,
+ * launch_grad_assembly, upload_vertices, launch_vertex_upload) and csrc/rasterise_egl.cu
+ * (upload_background, download_pixels and their launchers) -- to compile unmodified with g++ and to
+ * run as one sequential "thread" on the host.  Nothing here restates the reference's algorithm; it only
  * models the containers and intrinsics the algorithm is written against:
  *
  *   TTypes<T,N>::Tensor / ConstTensor   Eigen::TensorMap, row-major, operator() WITHOUT bounds checks
  *                                       (so pixels(iib,y,x,1) on a 1-channel tensor aliases the next
  *                                       float exactly as Eigen's index arithmetic does: quirk Q1)
  *   tensorflow::Tensor                  shape + borrowed buffer, tensor<T,N>(), dim_size(), NumElements()
- *   surf2Dread<float4>                  read of a float4 texel from a row-major host array
+ *   surf2Dread<float4> / surf2Dwrite    read / write of a float4 texel of a row-major host array
  *                                       (x is a byte offset, as in CUDA)
  *   atomicAdd(float*, float)            plain fp32 add (one thread => the kernel's own pixel order)
  *   cudaMemsetAsync, surface objects    memset / pass-through handles
@@ -52,7 +53,7 @@ typedef void *cudaStream_t;
 typedef int cudaError_t;
 
 /* A "cudaArray": a row-major float4 image on the host. */
-struct RefShimArray { float4 const *texels; int width, height; };
+struct RefShimArray { float4 *texels; int width, height; };
 typedef RefShimArray const *cudaArray_t;
 typedef RefShimArray const *cudaSurfaceObject_t;
 
@@ -73,6 +74,10 @@ template <class T> inline T surf2Dread(cudaSurfaceObject_t surface, int x_bytes,
 template <> inline float4 surf2Dread<float4>(cudaSurfaceObject_t surface, int x_bytes, int y) {
     return surface->texels[(size_t) y * surface->width + x_bytes / 16];
 }
+inline void surf2Dwrite(float4 const &value, cudaSurfaceObject_t surface, int x_bytes, int y) {
+    surface->texels[(size_t) y * surface->width + x_bytes / 16] = value;
+}
+inline char const *cudaGetErrorName(cudaError_t) { return "cudaError (host shim)"; }
 
 inline float atomicAdd(float *address, float value) { float const old = *address; *address = old + value; return old; }
 

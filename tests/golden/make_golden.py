@@ -6,7 +6,8 @@ absent; its kernels are DEVICE_GPU only) and it ships no stored expected arrays.
     parity tolerance refers to), pinned by tests/test_oracle.py;
   * ref_grads.npz (`--ref`, needs /root/reference): for the same cases, the output of the REFERENCE'S OWN
     `assemble_grads` / `launch_grad_assembly` compiled for the host (oracle/make_ref.py), fed the oracle's
-    visibility surfaces.  tests/test_oracle_ref.py requires the oracle to reproduce these bit for bit
+    visibility surfaces, and `pixels` = the reference's own upload_background / download_pixels around the oracle's
+    flip-free GL draw.  tests/test_oracle_ref.py requires the oracle to reproduce these bit for bit
     wherever the tests run (the reference itself does not travel to the GPU box).
 
 Run from the repository root:  python -m tests.golden.make_golden [--ref]
@@ -91,6 +92,8 @@ def main_ref():
         r = ref.backward(s['vertices'], s['faces'], px, s['grad_pixels'])
         for k, v in r.items():
             out[name + '/' + k] = v
+        # forward: the reference's own upload_background / download_pixels around the oracle's flip-free GL draw
+        out[name + '/pixels'] = ref.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
     path = os.path.join(HERE, 'ref_grads.npz')
     np.savez_compressed(path, **out)
     print('ref_grads.npz: %d arrays, %d bytes' % (len(out), os.path.getsize(path)))

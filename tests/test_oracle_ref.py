@@ -144,6 +144,37 @@ def test_oracle_reproduces_committed_reference_vectors(oracle, name):
     z = np.load(os.path.join(GOLDEN, 'ref_grads.npz'))
     b = make_golden.make_inputs(make_golden.CASES[name])
     px = oracle.forward(b['background'], b['vertices'], b['vertex_colors'], b['faces'])
+    assert np.array_equal(_bits(px), _bits(z[name + '/pixels'])), (name, 'pixels')   # reference movers around the flip-free draw
     got = oracle.backward(b['vertices'], b['faces'], px, b['grad_pixels'], flags=oracle.FLAG_F32_SEQUENTIAL, want_debug=True)
     for k in OUTPUTS:
         assert np.array_equal(_bits(got[k]), _bits(z[name + '/' + k])), (name, k)
+
+
+# ------------------------------------------------------------------------------------ forward data movers
+
+FORWARD_CASES = {
+    'orientation_triangle_c3': lambda: dict(
+        background=np.random.default_rng(0).uniform(0, 1, (1, 40, 60, 3)).astype(np.float32),
+        vertices=np.array([[[0.5, 0.5, 0, 1], [0.9, 0.5, 0, 1], [0.7, 0.9, 0, 1]]], np.float32),   # clip y > 0: the TOP of the image
+        vertex_colors=np.array([[[1, 0, 0], [0, 1, 0], [0, 0, 1]]], np.float32), faces=np.array([[[0, 1, 2]]], np.int32)),
+    'cylinder': lambda: _batch(scenes.cylinder_scene()),
+    'c1_batch3_atlas_2x2': lambda: scenes.batch_scene(200, 48, 36, 1, seeds=[1, 2, 3], r_lo=0.03, r_hi=0.2),
+    'c4_groups_3_1_batch2': lambda: scenes.batch_scene(150, 33, 47, 4, seeds=[5, 6], r_lo=0.05, r_hi=0.3),
+    'hostile_c3': lambda: _batch(scenes.hostile_scene(40, 56, 3, seed=8)),
+}
+
+
+@pytest.mark.parametrize('name', sorted(FORWARD_CASES))
+def test_oracle_forward_equals_reference_movers_around_a_flip_free_draw(oracle, ref, name):
+    """The forward op is upload_background -> GL draw -> download_pixels (csrc/rasterise_egl.cpp:348-392).  The two movers are
+    the reference's own code (csrc/rasterise_egl.cu compiled for the host): the vertical flip, the atlas tiling, the
+    replication of a single channel.  The draw between them is `oracle.draw_gl`, which addresses samples by GL window
+    coordinates only and knows nothing about tensor rows.  Their composition must equal `oracle.forward`, which works in
+    tensor orientation throughout: the forward restatement's y orientation and scene placement are then the reference's."""
+    b = FORWARD_CASES[name]()
+    want = ref.forward(b['background'], b['vertices'], b['vertex_colors'], b['faces'])
+    got = oracle.forward(b['background'], b['vertices'], b['vertex_colors'], b['faces'])
+    assert np.array_equal(_bits(got), _bits(want)), '%s: %d pixel values differ' % (name, int(np.sum(_bits(got) != _bits(want))))
+    if name == 'orientation_triangle_c3':
+        rows = np.nonzero((got[0] != b['background'][0]).any(-1))[0]
+        assert rows.size and rows.max() <= 10 and rows.min() >= 2      # rows (1 - y) / 2 * 40 for y in [0.5, 0.9]
