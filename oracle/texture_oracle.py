@@ -6,6 +6,8 @@ tests/ may import it; dirt_amd never does.
 expression, accumulated in float64.  Where the reference's gather_nd would read row Ht / column Wt (an index inside the
 last texel) the last texel is used (a documented choice of this build; TF's GPU gather_nd returns zeros there, its CPU
 kernel raises).  Parity: the reference ships no expected values for its samples; these functions are pinned by the
+reference's own two functions executed over a numpy stand-in for TensorFlow (tests/test_helpers_ref.py, committed
+vectors tests/golden/helpers_ref.npz: equal wherever the reference's gather_nd stays inside the texture) and by the
 analytic cases in tests/test_texture.py (texel centres, linear ramps)."""
 import numpy as np
 

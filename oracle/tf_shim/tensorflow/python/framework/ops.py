@@ -1,0 +1,7 @@
+"""`tensorflow.python.framework.ops` of the numpy stand-in (oracle/tf_shim/tensorflow/__init__.py): name scopes only."""
+import contextlib
+
+
+@contextlib.contextmanager
+def name_scope(name, default_name=None, values=None):
+    yield name or default_name
