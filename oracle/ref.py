@@ -10,7 +10,10 @@ What is the reference's and what is not:
     (csrc/rasterise_grad_egl.cpp:432-456, csrc/shaders.cpp:45-79); here they are filled from the
     oracle's specification-pinned visibility (`oracle.visibility`), over the reference's clear values
     (csrc/rasterise_grad_egl.cpp:442-445), in the reference's atlas layout (:408-428);
-  * the channel-group loop is dirt/rasterise_ops.py:132-177 restated over numpy (TensorFlow is absent).
+  * the channel-group loops of `forward` / `backward` below are dirt/rasterise_ops.py:86-108,132-177 restated over numpy
+    (they also run where /root/reference is absent); `python_layer()` is the reference's rasterise_ops.py ITSELF, imported
+    over a numpy stand-in for TensorFlow and bound to the kernels above -- tests/test_oracle_ref.py requires both routes,
+    and the reference's deferred wrapper with its gradient closure, to equal the oracle bit for bit.
 """
 import ctypes
 import math
@@ -181,6 +184,60 @@ def forward(background, vertices, vertex_colors, faces):
         pixels.append(rasterise_op(background[..., begin_channel:end_channel], vertices, vertex_colors[..., begin_channel:end_channel], faces))
         begin_channel = end_channel
     return np.concatenate(pixels, -1)
+
+
+_python_layer = None
+
+
+def python_layer():
+    """The reference's OWN Python op layer -- /root/reference/dirt/rasterise_ops.py, imported from where it lies over the
+    numpy TensorFlow stand-in (oracle/tf_shim) -- with its `_rasterise_module` bound to the host-compiled reference kernels
+    above: `.rasterise` = rasterise_op (reference upload / download around the oracle's flip-free GL draw), `.rasterise_grad` =
+    rasterise_grad_op (the reference's assemble_grads on the oracle's surfaces).  `rasterise`, `rasterise_batch`,
+    `_rasterise_grad_multichannel` and the forward half of the deferred wrappers then run as the reference wrote them:
+    dtype coercion, channel grouping, concatenation, the float32 sum of grad_vertices over groups."""
+    global _python_layer
+    if _python_layer is not None:
+        return _python_layer
+    import collections
+    import importlib.util
+    import os
+    import sys
+    path = '/root/reference/dirt/rasterise_ops.py'
+    if not os.path.exists(path):
+        raise RuntimeError('/root/reference is not present')
+    shim = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tf_shim')
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == 'tensorflow' or k.startswith('tensorflow.')}
+    sys.path.insert(0, shim)
+    try:
+        import tensorflow as tf_shim
+        result = collections.namedtuple('RasteriseGrad', ['grad_background', 'grad_vertices', 'grad_vertex_colors', 'debug_thingy'])
+
+        class OpLibrary:   # the attributes of the module tf.load_op_library returns (dirt/rasterise_ops.py:81-85,113-118)
+            @staticmethod
+            def rasterise(background, vertices, vertex_colors, faces, height, width, channels, name=None):
+                b = np.asarray(background)
+                assert b.shape[1:] == (height, width, channels)
+                return tf_shim.convert_to_tensor(rasterise_op(b, np.asarray(vertices), np.asarray(vertex_colors), np.asarray(faces)))
+
+            @staticmethod
+            def rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, channels, name=None):
+                out = rasterise_grad_op(np.asarray(vertices), np.asarray(faces), np.asarray(pixels), np.asarray(grad_pixels))
+                return result(*[tf_shim.convert_to_tensor(out[k]) for k in result._fields])
+
+        tf_shim._op_library = OpLibrary
+        spec = importlib.util.spec_from_file_location('dirt_reference_rasterise_ops', path)
+        module = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(module)
+        assert module._rasterise_module is OpLibrary
+        module.tf_shim = tf_shim
+        _python_layer = module
+        return module
+    finally:
+        sys.path.remove(shim)
+        for k in [k for k in sys.modules if k == 'tensorflow' or k.startswith('tensorflow.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
 
 
 def upload_vertices(vertices, faces):

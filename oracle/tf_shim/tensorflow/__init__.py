@@ -306,3 +306,43 @@ class version:   # noqa: N801
 @contextlib.contextmanager
 def device(_):
     yield
+
+
+# ---- what dirt/rasterise_ops.py needs on top of the helpers: the op library and (forward-only) custom_gradient ----------
+
+_op_library = None      # set by oracle/ref.py before the reference's module is imported: an object with .rasterise / .rasterise_grad
+_gradients_hook = None  # optional: tf.gradients(ys, xs, grad_ys) for the shader of rasterise_deferred (the caller's autodiff)
+
+
+def load_op_library(path):
+    if _op_library is None:
+        raise RuntimeError('no op library bound (oracle/ref.py binds the host-compiled reference kernels)')
+    return _op_library
+
+
+def executing_eagerly():
+    return False
+
+
+def gradients(ys, xs, grad_ys=None):
+    if _gradients_hook is None:
+        raise NotImplementedError('tf.gradients: no autodiff in the numpy stand-in; bind tensorflow._gradients_hook')
+    return _gradients_hook(ys, xs, grad_ys)
+
+
+class _WithGradient:
+    """What tf.custom_gradient makes of `f`: calling it gives the forward value; the gradient closure f returned is kept
+    on the value as `.dirt_grad_fn` so that a test can invoke the reference's backward composition directly."""
+
+    def __init__(self, f):
+        self.f = f
+
+    def __call__(self, *args, **kw):
+        value, grad_fn = self.f(*args, **kw)
+        value = _wrap(value)
+        value.dirt_grad_fn = grad_fn
+        return value
+
+
+def custom_gradient(f):
+    return _WithGradient(f)

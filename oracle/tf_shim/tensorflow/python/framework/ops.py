@@ -5,3 +5,10 @@ import contextlib
 @contextlib.contextmanager
 def name_scope(name, default_name=None, values=None):
     yield name or default_name
+
+
+def RegisterGradient(op_type):   # noqa: N802  (TensorFlow's name)
+    """Registering a gradient function is a no-op here: nothing differentiates through the stand-in."""
+    def decorator(fn):
+        return fn
+    return decorator

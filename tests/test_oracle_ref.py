@@ -178,3 +178,100 @@ def test_oracle_forward_equals_reference_movers_around_a_flip_free_draw(oracle, 
     if name == 'orientation_triangle_c3':
         rows = np.nonzero((got[0] != b['background'][0]).any(-1))[0]
         assert rows.size and rows.max() <= 10 and rows.min() >= 2      # rows (1 - y) / 2 * 40 for y in [0.5, 0.9]
+
+
+# ------------------------------------------------------------------------------- the reference's Python op layer
+
+@pytest.fixture(scope='module')
+def layer(ref):
+    """dirt/rasterise_ops.py itself (imported from /root/reference over the numpy TensorFlow stand-in), its op library
+    bound to the host-compiled reference kernels (oracle/ref.py::python_layer)."""
+    import os
+    if not os.path.exists('/root/reference/dirt/rasterise_ops.py'):
+        pytest.skip('/root/reference is not present')
+    return ref.python_layer()
+
+
+@pytest.mark.parametrize('channels', [1, 2, 3, 4, 5, 7])
+def test_reference_python_layer_equals_oracle(oracle, layer, channels):
+    """`rasterise_batch` (dirt/rasterise_ops.py:51-108: dtype coercion, H/W/C inference, channel grouping, concatenation) and
+    `_rasterise_grad_multichannel` (:132-177: per-group grad ops, float32 sum of grad_vertices) are the reference's own
+    functions here, running on the reference's own kernels; the oracle's single-pass forward and its grouped backward must
+    equal them bit for bit.  So the whole stack above the GL draw is the reference's code."""
+    t = layer.tf_shim.convert_to_tensor
+    b = scenes.batch_scene(120, 30, 44, channels, seeds=[5, 6, 7], r_lo=0.05, r_hi=0.3)
+    px = np.asarray(layer.rasterise_batch(b['background'], b['vertices'], b['vertex_colors'], b['faces']))
+    want = oracle.forward(b['background'], b['vertices'], b['vertex_colors'], b['faces'])
+    assert np.array_equal(_bits(px), _bits(want))
+    g = layer._rasterise_grad_multichannel(t(b['vertices']), t(b['faces']), t(want), t(b['grad_pixels']), 'batch')
+    o = oracle.backward(b['vertices'], b['faces'], want, b['grad_pixels'], flags=oracle.FLAG_F32_SEQUENTIAL)
+    for k in ('grad_vertices', 'grad_vertex_colors', 'grad_background'):
+        assert np.array_equal(_bits(np.asarray(g[k])), _bits(o[k])), (channels, k)
+    # the single-scene entry points (:13-48, 'single' of :138-143)
+    one = {k: b[k][1] for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
+    px1 = np.asarray(layer.rasterise(one['background'], one['vertices'], one['vertex_colors'], one['faces']))
+    want1 = oracle.forward(one['background'][None], one['vertices'][None], one['vertex_colors'][None], one['faces'][None])[0]
+    assert np.array_equal(_bits(px1), _bits(want1))
+    g1 = layer._rasterise_grad_multichannel(t(one['vertices']), t(one['faces']), t(want1), t(one['grad_pixels']), 'single')
+    o1 = oracle.backward(one['vertices'][None], one['faces'][None], want1[None], one['grad_pixels'][None], flags=oracle.FLAG_F32_SEQUENTIAL)
+    for k in ('grad_vertices', 'grad_vertex_colors', 'grad_background'):
+        assert np.array_equal(_bits(np.asarray(g1[k])), _bits(o1[k][0])), (channels, k, 'single')
+
+
+def test_reference_deferred_composition(oracle, layer):
+    """`rasterise_deferred` (dirt/rasterise_ops.py:180-310) end to end in the reference's own code: G-buffer by its
+    `rasterise`, the shader, and its `grad` closure -- vertex gradients from filtering the SHADED image, attribute and
+    background gradients from the G-buffer with dL/dgbuffer (:204-237).  The one thing the stand-in cannot do, differentiate
+    the shader (`tf.gradients`), is handed to torch.  The GPU tests compare dirt_amd's deferred path with exactly this
+    composition written out on the oracle (tests/test_gpu_fullsize.py::_deferred_reference): here that composition is
+    checked against the reference's."""
+    import torch
+    tf_shim = layer.tf_shim
+    t = tf_shim.convert_to_tensor
+    clip, faces, world, colours = scenes.bent_square_geometry()
+    tri = world[:, :3].reshape(-1, 3, 3)
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    attrs = np.concatenate([np.ones([6, 1]), colours, np.repeat(n, 3, axis=0)], axis=1).astype(np.float32)   # mask, colour, normal
+    H = W = 32
+    bg_attrs = np.zeros([H, W, 7], np.float32)
+    light = np.float32([0.3, 0.8, 0.5])
+    graphs = {}
+
+    def shader_fn(gbuffer, light_):
+        g = torch.tensor(np.asarray(gbuffer), requires_grad=True)
+        l = torch.tensor(np.asarray(light_), requires_grad=True)
+        mask, cols, nrm = g[..., :1], g[..., 1:4], g[..., 4:7]
+        px = mask * cols * (0.3 + (nrm * l).sum(-1, keepdim=True).abs()) + (1. - mask) * 0.1
+        out = t(px.detach().numpy())
+        graphs[id(out)] = (px, {id(gbuffer): g, id(light_): l})
+        return out
+
+    def gradients(ys, xs, grad_ys):
+        px, inputs = graphs[id(ys)]
+        grads = torch.autograd.grad(px, [inputs[id(x)] for x in xs], torch.tensor(np.asarray(grad_ys)))
+        return [t(g.numpy()) for g in grads]
+
+    tf_shim._gradients_hook = gradients
+    try:
+        pixels = layer.rasterise_deferred(bg_attrs, clip, attrs, faces, shader_fn, [light])
+        d = np.random.default_rng(3).standard_normal((H, W, 3)).astype(np.float32)
+        d_vertices, d_faces, d_attributes, d_background, d_light = pixels.dirt_grad_fn(t(d))
+    finally:
+        tf_shim._gradients_hook = None
+    assert d_faces is None
+    # the same composition written out on the oracle
+    gbuf = oracle.forward(bg_attrs[None], clip[None], attrs[None], faces[None])
+    gt = torch.tensor(gbuf[0], requires_grad=True)
+    lt = torch.tensor(light, requires_grad=True)
+    mask, cols, nrm = gt[..., :1], gt[..., 1:4], gt[..., 4:7]
+    shaded = mask * cols * (0.3 + (nrm * lt).sum(-1, keepdim=True).abs()) + (1. - mask) * 0.1
+    assert np.array_equal(_bits(np.asarray(pixels)), _bits(shaded.detach().numpy()))
+    shaded.backward(torch.tensor(d))
+    seq = oracle.FLAG_F32_SEQUENTIAL
+    want_v = oracle.backward(clip[None], faces[None], shaded.detach().numpy()[None], d[None], flags=seq)
+    want_a = oracle.backward(clip[None], faces[None], gbuf, gt.grad.numpy()[None], flags=seq)
+    assert np.array_equal(_bits(np.asarray(d_vertices)), _bits(want_v['grad_vertices'][0]))
+    assert np.array_equal(_bits(np.asarray(d_attributes)), _bits(want_a['grad_vertex_colors'][0]))
+    assert np.array_equal(_bits(np.asarray(d_background)), _bits(want_a['grad_background'][0]))
+    assert np.allclose(np.asarray(d_light), lt.grad.numpy())
