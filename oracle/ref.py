@@ -189,6 +189,56 @@ def forward(background, vertices, vertex_colors, faces):
 _python_layer = None
 
 
+def _op_library_for(tf_shim):
+    """The attributes of the module tf.load_op_library returns (dirt/rasterise_ops.py:81-85,113-118), on the host-compiled kernels."""
+    import collections
+    result = collections.namedtuple('RasteriseGrad', ['grad_background', 'grad_vertices', 'grad_vertex_colors', 'debug_thingy'])
+
+    class OpLibrary:
+        @staticmethod
+        def rasterise(background, vertices, vertex_colors, faces, height, width, channels, name=None):
+            b = np.asarray(background)
+            assert b.shape[1:] == (height, width, channels)
+            return tf_shim.convert_to_tensor(rasterise_op(b, np.asarray(vertices), np.asarray(vertex_colors), np.asarray(faces)))
+
+        @staticmethod
+        def rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, channels, name=None):
+            out = rasterise_grad_op(np.asarray(vertices), np.asarray(faces), np.asarray(pixels), np.asarray(grad_pixels))
+            return result(*[tf_shim.convert_to_tensor(out[k]) for k in result._fields])
+
+    return OpLibrary
+
+
+def run_reference_script(path, entry='main'):
+    """Run one of the reference's own scripts (e.g. /root/reference/tests/square_test.py) VERBATIM: `import tensorflow` gives
+    the numpy stand-in, `import dirt` the reference's own package (dirt/__init__.py, dirt/rasterise_ops.py) with its op
+    library bound to the host-compiled kernels and the oracle's GL draw.  Returns what it printed."""
+    import contextlib
+    import importlib.util
+    import io
+    import os
+    import sys
+    shim = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tf_shim')
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules)
+             if k in ('tensorflow', 'dirt') or k.startswith('tensorflow.') or k.startswith('dirt.')}
+    sys.path[:0] = [shim, '/root/reference']
+    try:
+        import tensorflow as tf_shim
+        tf_shim._op_library = _op_library_for(tf_shim)
+        spec = importlib.util.spec_from_file_location('dirt_reference_script', path)
+        module = importlib.util.module_from_spec(spec)
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            spec.loader.exec_module(module)
+            getattr(module, entry)()
+        return out.getvalue()
+    finally:
+        del sys.path[:2]
+        for k in [k for k in sys.modules if k in ('tensorflow', 'dirt') or k.startswith('tensorflow.') or k.startswith('dirt.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
 def python_layer():
     """The reference's OWN Python op layer -- /root/reference/dirt/rasterise_ops.py, imported from where it lies over the
     numpy TensorFlow stand-in (oracle/tf_shim) -- with its `_rasterise_module` bound to the host-compiled reference kernels
@@ -199,7 +249,6 @@ def python_layer():
     global _python_layer
     if _python_layer is not None:
         return _python_layer
-    import collections
     import importlib.util
     import os
     import sys
@@ -211,20 +260,7 @@ def python_layer():
     sys.path.insert(0, shim)
     try:
         import tensorflow as tf_shim
-        result = collections.namedtuple('RasteriseGrad', ['grad_background', 'grad_vertices', 'grad_vertex_colors', 'debug_thingy'])
-
-        class OpLibrary:   # the attributes of the module tf.load_op_library returns (dirt/rasterise_ops.py:81-85,113-118)
-            @staticmethod
-            def rasterise(background, vertices, vertex_colors, faces, height, width, channels, name=None):
-                b = np.asarray(background)
-                assert b.shape[1:] == (height, width, channels)
-                return tf_shim.convert_to_tensor(rasterise_op(b, np.asarray(vertices), np.asarray(vertex_colors), np.asarray(faces)))
-
-            @staticmethod
-            def rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, channels, name=None):
-                out = rasterise_grad_op(np.asarray(vertices), np.asarray(faces), np.asarray(pixels), np.asarray(grad_pixels))
-                return result(*[tf_shim.convert_to_tensor(out[k]) for k in result._fields])
-
+        OpLibrary = _op_library_for(tf_shim)
         tf_shim._op_library = OpLibrary
         spec = importlib.util.spec_from_file_location('dirt_reference_rasterise_ops', path)
         module = importlib.util.module_from_spec(spec)

@@ -14,6 +14,7 @@ import contextlib
 import numpy as np
 
 newaxis = None
+__version__ = '2.0.0'   # the reference's scripts take their eager (`.numpy()`) branch
 float32, float64, int32, int64 = np.dtype('float32'), np.dtype('float64'), np.dtype('int32'), np.dtype('int64')
 
 
@@ -95,6 +96,9 @@ class Tensor:
     def __int__(self): return int(self.a)
     def __index__(self): return int(self.a)
     def __float__(self): return float(self.a)
+
+    def numpy(self):
+        return self.a
 
 
 def _wrap(a):
@@ -250,6 +254,22 @@ def scatter_nd(indices, updates, shape):   # noqa: A002
     idx = np.asarray(_raw(indices))
     np.add.at(out, tuple(idx[:, k] for k in np.arange(idx.shape[1])), np.asarray(_raw(updates)))
     return _wrap(out)
+
+
+def ones(shape_, dtype=float32):
+    return _wrap(np.ones(_ints(shape_) if not isinstance(shape_, int) else [shape_], dtype))
+
+
+def meshgrid(*args):
+    return [_wrap(a) for a in np.meshgrid(*[np.asarray(_raw(x)) for x in args])]
+
+
+def less_equal(a, b):
+    return _wrap(np.asarray(_raw(convert_to_tensor(a))) <= np.asarray(_raw(convert_to_tensor(b))).astype(np.asarray(_raw(a)).dtype))
+
+
+def logical_and(a, b):
+    return _wrap(np.logical_and(np.asarray(_raw(a)), np.asarray(_raw(b))))
 
 
 def floor(t):

@@ -275,3 +275,14 @@ def test_reference_deferred_composition(oracle, layer):
     assert np.array_equal(_bits(np.asarray(d_attributes)), _bits(want_a['grad_vertex_colors'][0]))
     assert np.array_equal(_bits(np.asarray(d_background)), _bits(want_a['grad_background'][0]))
     assert np.allclose(np.asarray(d_light), lt.grad.numpy())
+
+
+def test_reference_square_test_script_runs_verbatim(ref):
+    """/root/reference/tests/square_test.py -- the reference's only known-answer test -- executed AS IT IS: its `import
+    tensorflow` finds the numpy stand-in, its `import dirt` the reference's own package, whose op library is the
+    host-compiled reference movers around the oracle's GL draw.  It must print its success line (:54-57)."""
+    import os
+    path = '/root/reference/tests/square_test.py'
+    if not os.path.exists(path):
+        pytest.skip('/root/reference is not present')
+    assert ref.run_reference_script(path) == 'successful: all pixels agree\n'
