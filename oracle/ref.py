@@ -212,17 +212,26 @@ def _op_library_for(tf_shim):
 def run_reference_script(path, entry='main'):
     """Run one of the reference's own scripts (e.g. /root/reference/tests/square_test.py) VERBATIM: `import tensorflow` gives
     the numpy stand-in, `import dirt` the reference's own package (dirt/__init__.py, dirt/rasterise_ops.py) with its op
-    library bound to the host-compiled kernels and the oracle's GL draw.  Returns what it printed."""
+    library bound to the host-compiled kernels and the oracle's GL draw; `import cv2` (the samples display their result)
+    gives a stub that records what is shown.  Returns what the script printed; `run_reference_script.images` then holds
+    the (window name, image) pairs it showed."""
     import contextlib
     import importlib.util
     import io
     import os
     import sys
     shim = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tf_shim')
+    import types
     saved = {k: sys.modules.pop(k) for k in list(sys.modules)
-             if k in ('tensorflow', 'dirt') or k.startswith('tensorflow.') or k.startswith('dirt.')}
+             if k in ('tensorflow', 'dirt', 'cv2') or k.startswith('tensorflow.') or k.startswith('dirt.')}
     sys.path[:0] = [shim, '/root/reference']
+    run_reference_script.images = shown = []
+    cv2 = types.ModuleType('cv2')
+    cv2.imshow = lambda name, image: shown.append((name, np.array(image)))
+    cv2.waitKey = lambda *a: 0
+    cv2.imwrite = lambda name, image: shown.append((name, np.array(image))) or True
     try:
+        sys.modules['cv2'] = cv2
         import tensorflow as tf_shim
         tf_shim._op_library = _op_library_for(tf_shim)
         spec = importlib.util.spec_from_file_location('dirt_reference_script', path)
@@ -234,7 +243,7 @@ def run_reference_script(path, entry='main'):
         return out.getvalue()
     finally:
         del sys.path[:2]
-        for k in [k for k in sys.modules if k in ('tensorflow', 'dirt') or k.startswith('tensorflow.') or k.startswith('dirt.')]:
+        for k in [k for k in sys.modules if k in ('tensorflow', 'dirt', 'cv2') or k.startswith('tensorflow.') or k.startswith('dirt.')]:
             del sys.modules[k]
         sys.modules.update(saved)
 

@@ -100,6 +100,9 @@ class Tensor:
     def numpy(self):
         return self.a
 
+    def eval(self, feed_dict=None):   # noqa: A003  (TensorFlow 1.x: everything is already evaluated here)
+        return self.a
+
 
 def _wrap(a):
     return a if isinstance(a, Tensor) else Tensor(a)
@@ -326,6 +329,20 @@ class version:   # noqa: N801
 @contextlib.contextmanager
 def device(_):
     yield
+
+
+class Session:
+    """tf.Session of the 1.x scripts: nothing to hold, every tensor is already a value."""
+
+    def __init__(self, *args, **kw):
+        pass
+
+    @contextlib.contextmanager
+    def as_default(self):
+        yield self
+
+    def run(self, fetches, feed_dict=None):
+        return [np.asarray(_raw(f)) for f in fetches] if isinstance(fetches, (list, tuple)) else np.asarray(_raw(fetches))
 
 
 # ---- what dirt/rasterise_ops.py needs on top of the helpers: the op library and (forward-only) custom_gradient ----------

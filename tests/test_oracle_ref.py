@@ -286,3 +286,38 @@ def test_reference_square_test_script_runs_verbatim(ref):
     if not os.path.exists(path):
         pytest.skip('/root/reference is not present')
     assert ref.run_reference_script(path) == 'successful: all pixels agree\n'
+
+
+def test_reference_simple_sample_runs_verbatim_and_matches_the_port(oracle, ref):
+    """/root/reference/samples/simple.py executed AS IT IS (numpy TensorFlow stand-in, the reference's own dirt package, a
+    recording cv2 stub): the image it shows equals, to float rounding of the matrix helpers, what this repository's port of
+    the sample (examples/simple.py's pipeline over dirt_amd.matrices / lighting) hands to the rasteriser, rendered by the
+    oracle -- and the GPU tests check examples/simple.py against the oracle bit for bit (tests/test_gpu_fullsize.py)."""
+    import os
+    import torch
+    path = '/root/reference/samples/simple.py'
+    if not os.path.exists(path):
+        pytest.skip('/root/reference is not present')
+    ref.run_reference_script(path)
+    (name, shown), = ref.run_reference_script.images
+    reference_image = shown[:, :, ::-1]   # the sample shows BGR (samples/simple.py:78)
+    assert reference_image.shape == (480, 640, 3)
+
+    from dirt_amd import lighting, matrices
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('example_simple', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'simple.py'))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    vertices, faces = ex.build_cube()
+    v, f = lighting.split_vertices_by_face(torch.tensor(vertices, dtype=torch.float32), torch.tensor(faces, dtype=torch.int32))
+    colors = torch.ones_like(v)
+    v = torch.cat([v, torch.ones_like(v[:, -1:])], dim=1)
+    world = v @ matrices.rodrigues(torch.tensor([0., 0.5, 0.]))
+    normals = lighting.vertex_normals_pre_split(world, f)
+    view = matrices.compose(matrices.translation(torch.tensor([0., -1.5, -3.5])), matrices.rodrigues(torch.tensor([-0.3, 0., 0.])))
+    clip = (world @ view) @ matrices.perspective_projection(near=0.1, far=20., right=0.1, aspect=480. / 640.)
+    lit = lighting.diffuse_directional(normals, colors, light_direction=torch.tensor([1., 0., 0.]), light_color=torch.tensor([1., 1., 1.])) * 0.8 + colors * 0.2
+    ours = oracle.forward(np.zeros((1, 480, 640, 3), np.float32), clip.numpy()[None], lit.numpy()[None], f.numpy()[None])[0]
+    differing = np.abs(ours - reference_image).max(-1) > 1e-5
+    assert differing.mean() < 2e-4, 'the port of samples/simple.py and the sample itself differ in %d pixels' % int(differing.sum())
+    assert 0.1 < float((reference_image.sum(-1) > 0).mean()) < 0.6
