@@ -213,8 +213,8 @@ def run_reference_script(path, entry='main'):
     """Run one of the reference's own scripts (e.g. /root/reference/tests/square_test.py) VERBATIM: `import tensorflow` gives
     the numpy stand-in, `import dirt` the reference's own package (dirt/__init__.py, dirt/rasterise_ops.py) with its op
     library bound to the host-compiled kernels and the oracle's GL draw; `import cv2` (the samples display their result)
-    gives a stub that records what is shown.  Returns what the script printed; `run_reference_script.images` then holds
-    the (window name, image) pairs it showed."""
+    gives a stub that records what is shown, and tf.write_file records instead of writing.  Returns what the script printed;
+    `run_reference_script.images` then holds the (window or file name, image) pairs it showed or wrote."""
     import contextlib
     import importlib.util
     import io
@@ -234,6 +234,7 @@ def run_reference_script(path, entry='main'):
         sys.modules['cv2'] = cv2
         import tensorflow as tf_shim
         tf_shim._op_library = _op_library_for(tf_shim)
+        tf_shim.written_files = shown   # tf.write_file(name, tf.image.encode_jpeg(uint8 image)) lands in the same list
         spec = importlib.util.spec_from_file_location('dirt_reference_script', path)
         module = importlib.util.module_from_spec(spec)
         out = io.StringIO()

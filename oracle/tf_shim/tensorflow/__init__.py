@@ -16,6 +16,7 @@ import numpy as np
 newaxis = None
 __version__ = '2.0.0'   # the reference's scripts take their eager (`.numpy()`) branch
 float32, float64, int32, int64 = np.dtype('float32'), np.dtype('float64'), np.dtype('int32'), np.dtype('int64')
+uint8 = np.dtype('uint8')
 
 
 class _Dim(int):
@@ -312,7 +313,17 @@ def sparse_reduce_sum(sp, axis=None):
     return _wrap(dense.sum(axis=axis).astype(sp.values.dtype))
 
 
+def matrix_inverse(t):
+    a = np.asarray(_raw(t))
+    return _wrap(np.linalg.inv(a.astype(np.float64)).astype(a.dtype))
+
+
 class linalg:   # noqa: N801
+    @staticmethod
+    def l2_normalize(t, axis=None, epsilon=1e-12):
+        a = np.asarray(_raw(convert_to_tensor(t)))
+        return _wrap((a / np.sqrt(np.maximum(np.sum(a * a, axis=axis, keepdims=True), a.dtype.type(epsilon)))).astype(a.dtype))
+
     @staticmethod
     def diag(t):
         a = np.asarray(_raw(t))
@@ -343,6 +354,44 @@ class Session:
 
     def run(self, fetches, feed_dict=None):
         return [np.asarray(_raw(f)) for f in fetches] if isinstance(fetches, (list, tuple)) else np.asarray(_raw(fetches))
+
+
+# ---- what the reference's sample scripts do around their rendering: files, JPEG, session options -----------------------
+
+written_files = []   # (file name, contents) of every tf.write_file: nothing is written to disk
+
+
+class _Runnable:
+    def run(self, *args, **kw):
+        pass
+
+
+def write_file(filename, contents):
+    written_files.append((str(filename), np.asarray(_raw(contents))))
+    return _Runnable()
+
+
+def read_file(filename):
+    return str(filename)
+
+
+class image:   # noqa: N801
+    @staticmethod
+    def encode_jpeg(t):
+        return t          # (kept as the uint8 image: the comparison wants the pixels, not a codec)
+
+    @staticmethod
+    def decode_jpeg(path):
+        from PIL import Image
+        return _wrap(np.asarray(Image.open(path).convert('RGB'), dtype=np.uint8))
+
+
+def ConfigProto(**kw):   # noqa: N802
+    return None
+
+
+def GPUOptions(**kw):   # noqa: N802
+    return None
 
 
 # ---- what dirt/rasterise_ops.py needs on top of the helpers: the op library and (forward-only) custom_gradient ----------

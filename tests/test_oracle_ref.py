@@ -321,3 +321,72 @@ def test_reference_simple_sample_runs_verbatim_and_matches_the_port(oracle, ref)
     differing = np.abs(ours - reference_image).max(-1) > 1e-5
     assert differing.mean() < 2e-4, 'the port of samples/simple.py and the sample itself differ in %d pixels' % int(differing.sum())
     assert 0.1 < float((reference_image.sum(-1) > 0).mean()) < 0.6
+
+
+def _load_example(name):
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('example_' + name, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', name + '.py'))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    return ex
+
+
+def _close_images(ours_u8, reference_u8, what):
+    diff = np.abs(ours_u8.astype(np.int32) - reference_u8.astype(np.int32)).max(-1)
+    assert ours_u8.shape == reference_u8.shape
+    # the helpers' float rounding moves a value across an integer level here and there, and an edge pixel now and then
+    assert (diff > 1).mean() < 5e-4, '%s: %d pixels differ by more than one level' % (what, int((diff > 1).sum()))
+
+
+def test_reference_deferred_sample_runs_verbatim_and_matches_the_port(oracle, ref):
+    """/root/reference/samples/deferred.py as it is -- a 10-channel G-buffer through the reference's `rasterise_deferred`,
+    per-pixel ambient + diffuse + Phong lighting -- against examples/deferred.py's geometry and shader (this repository's port
+    of the sample) over the oracle's G-buffer."""
+    import os
+    import torch
+    path = '/root/reference/samples/deferred.py'
+    if not os.path.exists(path):
+        pytest.skip('/root/reference is not present')
+    ref.run_reference_script(path)
+    (name, reference_image), = ref.run_reference_script.images
+    assert name == 'deferred.jpg' and reference_image.dtype == np.uint8
+    ex = _load_example('deferred')
+    from dirt_amd import matrices
+    vertices, faces = (torch.from_numpy(a) for a in ex.build_cube())
+    view = matrices.compose(matrices.translation(torch.tensor([0., -1.5, -3.5])), matrices.rodrigues(torch.tensor([-0.3, 0., 0.])))
+    light = torch.nn.functional.normalize(torch.tensor([1., -0.3, -0.5]), dim=0)
+    clip, faces, attributes = ex.geometry(vertices, faces, view)
+    H, W = ex.frame_height, ex.frame_width
+    gbuf = oracle.forward(np.zeros((1, H, W, 10), np.float32), clip.numpy()[None], attributes.numpy()[None], faces.numpy()[None])[0]
+    ours = (ex.shader_fn(torch.from_numpy(gbuf), view, light) * 255).to(torch.uint8).numpy()
+    _close_images(ours, reference_image, 'deferred')
+    assert 0.1 < float((reference_image[..., 2] != 76).mean()) < 0.7   # background (0, 0, 0.3) * 255 = 76
+
+
+def test_reference_textured_sample_runs_verbatim_and_matches_the_port(oracle, ref):
+    """/root/reference/samples/textured.py as it is (its cat.jpg decoded by Pillow behind tf.image.decode_jpeg) against
+    examples/textured.py's geometry with the same texture, the look-up by dirt_amd.texture's two reference-named helpers."""
+    import os
+    import torch
+    path = '/root/reference/samples/textured.py'
+    if not os.path.exists(path):
+        pytest.skip('/root/reference is not present')
+    ref.run_reference_script(path)
+    (name, reference_image), = ref.run_reference_script.images
+    assert name == 'textured.jpg' and reference_image.dtype == np.uint8
+    ex = _load_example('textured')
+    from PIL import Image
+    from dirt_amd import lighting, texture as tex
+    texture = torch.from_numpy(np.array(Image.open('/root/reference/samples/cat.jpg').convert('RGB'), dtype=np.uint8)).to(torch.float32) / 255.
+    vertices, uvs, faces = (torch.from_numpy(a) for a in ex.build_cube())
+    light = torch.nn.functional.normalize(torch.tensor([1., -0.3, -0.5]), dim=0)
+    clip, attributes = ex.geometry(vertices, uvs, faces)
+    H, W = ex.frame_height, ex.frame_width
+    gbuf = torch.from_numpy(oracle.forward(np.zeros((1, H, W, 6), np.float32), clip.numpy()[None], attributes.numpy()[None], faces.numpy()[None])[0])
+    mask, uv, normals = gbuf[..., :1], gbuf[..., 1:3], gbuf[..., 3:]
+    unlit = tex.sample_texture(texture, tex.uvs_to_pixel_indices(uv, texture.shape[:2]))   # the example's fused look-up, unfused (CPU)
+    diffuse = lighting.diffuse_directional(normals.reshape(-1, 3), unlit.reshape(-1, 3), light, light_color=torch.full((3,), 0.6), double_sided=True)
+    shaded = (diffuse.reshape(unlit.shape) + unlit * 0.4) * mask + torch.tensor([0., 0., 0.3]) * (1. - mask)
+    ours = (shaded * 255).to(torch.uint8).numpy()
+    _close_images(ours, reference_image, 'textured')
