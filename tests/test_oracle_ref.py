@@ -390,3 +390,14 @@ def test_reference_textured_sample_runs_verbatim_and_matches_the_port(oracle, re
     shaded = (diffuse.reshape(unlit.shape) + unlit * 0.4) * mask + torch.tensor([0., 0., 0.3]) * (1. - mask)
     ours = (shaded * 255).to(torch.uint8).numpy()
     _close_images(ours, reference_image, 'textured')
+
+
+def test_reference_multi_gpu_script_runs_verbatim(ref):
+    """/root/reference/tests/multi_gpu_test.py as it is: the op under two `tf.device` scopes, evaluated in one session.  The
+    stand-in has no devices, so all this checks is that the script's graph runs on the stack and draws its square twice; the
+    two-device property itself is tests/test_gpu_configs.py::test_two_gpus_over_rccl (RCCL, one rank per GPU)."""
+    import os
+    path = '/root/reference/tests/multi_gpu_test.py'
+    if not os.path.exists(path):
+        pytest.skip('/root/reference is not present')
+    assert ref.run_reference_script(path) == ''
