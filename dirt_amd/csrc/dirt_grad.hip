@@ -641,7 +641,12 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             key[j] = covered[j] ? f_own[j] : -1;
         }
 
-        // ---- background gradient (:143-147): grad_pixels where nothing is covered, zero elsewhere ----
+        // ---- background gradient (:143-147): grad_pixels where nothing is covered, zero elsewhere.  Issued AFTER the face
+        //      loop: here, between the Scharr filter and the dilation, every wave of the chip reaches them at about the same
+        //      time (one lockstep round) and stalls behind 16.8 MB of stores (the per-wave trace: ~3000 clocks of the
+        //      dilation phase); at the end of a wave they spread over the ~10 us in which the waves finish.  What they need
+        //      -- grad_pixels and "covered" -- is live in the face loop anyway.  K3-2048: gradient kernel 69 -> 66 us. ----
+        auto store_background = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!in_px[j]) continue;
@@ -665,6 +670,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                 for (int ch = 0; ch < NCH; ++ch) st_off<float>(gbk_t, off + 4u * ch, covered[j] ? 0.f : g[j][ch]);
             }
         }
+        };
 
         // ---- dilation (:155-194).  A pixel takes the fragment of the neighbour n at +d, else at -d, when that neighbour
         //      is covered, is another face (:86-89) and is closer (:165); d is +-x or +-y.  An uncovered neighbour has
@@ -676,49 +682,53 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         //      clip_w -- perspective-correct barycentrics -- so no vertex gather is needed; one v_rcp_f32, 1 ulp; agrees to
         //      float rounding), everything taken at the pixel whose fragment is used.  (fx, fy) are summed per such
         //      TARGET pixel -- own pixels in registers, neighbours through the inbox -- and fw is formed once per pixel. ----
-        const lanemask parity0 = __builtin_amdgcn_ballot_w64(((xs + y) & 1) == 0);  // pixel 0 tries +x / up first (:186-191)
+        // Per pixel: the clip_w of each neighbour that would dilate into it -- another face (:86-89) that is closer (:165) --
+        // or 0; the attempt order of :186-193 is then two selects per pixel (by the parity dither) and two per channel
+        // group (by its axis), and "which neighbour, if any" two compares against 0.  A pixel's own fragment is the common
+        // case and runs unconditionally (one rcp of its own clip_w per pixel); the neighbour's clip_w, its reciprocal and
+        // the inbox address exist only for the few dilated lanes.  (Rounds 2-3 kept every predicate as a wave-wide lane
+        // mask combined on the scalar unit: ~40 masks alive, moved through VGPRs by the compiler, and every pixel a chain
+        // v_cmp -> s_and / s_or x 6 -> v_cndmask x 4; this form has 160 fewer scalar instructions per wave.)
+        const bool pos0 = ((xs + y) & 1) == 0;   // pixel 0 tries +x / up first (:186-191)
         const float2v half_size = float2v{.5f * width_f, .5f * height_f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float wl = j == 0 ? w_l : w_own[j - 1], wr = j == 3 ? w_r : w_own[j + 1];
             const int fl = j == 0 ? f_l : f_own[j - 1], fr = j == 3 ? f_r : f_own[j + 1];
-            // the pixel's own face as the state tile has it (an uncovered pixel, -1, differs from any face)
-            const lanemask m_in = __builtin_amdgcn_ballot_w64(interior[j]);
-            const lanemask ok_l = m_in & __builtin_amdgcn_ballot_w64(fl != f_own[j]) & __builtin_amdgcn_ballot_w64(w_own[j] > wl);
-            const lanemask ok_r = m_in & __builtin_amdgcn_ballot_w64(fr != f_own[j]) & __builtin_amdgcn_ballot_w64(w_own[j] > wr);
-            const lanemask ok_u = m_in & __builtin_amdgcn_ballot_w64(f_up[j] != f_own[j]) & __builtin_amdgcn_ballot_w64(w_own[j] > w_up[j]);
-            const lanemask ok_d = m_in & __builtin_amdgcn_ballot_w64(f_dn[j] != f_own[j]) & __builtin_amdgcn_ballot_w64(w_own[j] > w_dn[j]);
-            const lanemask m_cov = __builtin_amdgcn_ballot_w64(covered[j]);
-            const lanemask pos = (j & 1) ? ~parity0 : parity0;   // first attempt towards +x / up (:191), else -x / down
+            // (the pixel's own face as the state tile has it: an uncovered pixel, -1, differs from any face)
+            const float wo = interior[j] ? w_own[j] : -INFINITY;   // pixels on the frame's border are never dilated (:155)
+            const float qL = (fl != f_own[j]) & (wo > wl) ? wl : 0.f;
+            const float qR = (fr != f_own[j]) & (wo > wr) ? wr : 0.f;
+            const float qU = (f_up[j] != f_own[j]) & (wo > w_up[j]) ? w_up[j] : 0.f;
+            const float qD = (f_dn[j] != f_own[j]) & (wo > w_dn[j]) ? w_dn[j] : 0.f;
+            const bool pos = (j & 1) ? !pos0 : pos0;   // first attempt towards +x / up (:191), else -x / down
+            const float qx1 = pos ? qR : qL, qx2 = pos ? qL : qR, qy1 = pos ? qU : qD, qy2 = pos ? qD : qU;
+            const float rcp_own = __builtin_amdgcn_rcpf(w_own[j]);
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
                 if (STRIDED && NCH == 4 && gi == 1 && !single_on) continue;
                 // direction: x if L1(Sx) > L1(Sy) else y (:185), negated on odd (x + y) (:186-190).  The reference's
                 // offsets are in GL buffer orientation (y up): tensor row = y - offset_y.
-                const lanemask hz = horiz_m[gi][j];
-                const lanemask ok_a = (hz & ((pos & ok_r) | (~pos & ok_l))) | (~hz & ((pos & ok_u) | (~pos & ok_d)));
-                const lanemask ok_b = (hz & ((pos & ok_l) | (~pos & ok_r))) | (~hz & ((pos & ok_d) | (~pos & ok_u)));
-                const lanemask dil = ok_a | ok_b;      // the opposite direction if the first failed (:192-193)
-                const lanemask fwd = ~(pos ^ ok_a);    // the neighbour taken lies at +x / up
-                float clip_w = w_own[j];
-                clip_w = __builtin_amdgcn_inverse_ballot_w64(dil & hz & fwd) ? wr : clip_w;
-                clip_w = __builtin_amdgcn_inverse_ballot_w64(dil & hz & ~fwd) ? wl : clip_w;
-                clip_w = __builtin_amdgcn_inverse_ballot_w64(dil & ~hz & fwd) ? w_up[j] : clip_w;
-                clip_w = __builtin_amdgcn_inverse_ballot_w64(dil & ~hz & ~fwd) ? w_dn[j] : clip_w;
-                const bool dilated = __builtin_amdgcn_inverse_ballot_w64(dil);
+                const bool hz = __builtin_amdgcn_inverse_ballot_w64(horiz_m[gi][j]);
+                const float q1 = hz ? qx1 : qy1, q2 = hz ? qx2 : qy2;
+                const bool first = q1 != 0.f;                 // the first attempt found its neighbour
+                const bool dilated = first | (q2 != 0.f);     // ... or the opposite one did (:192-193)
                 if constexpr (DEBUG) {
                     if (cbase == 0 && gi == 0 && in_px[j]) write_debug(p.debug_thingy, p.grad_pixels, p.B, H, W, C, iib, y, xs + j, G0, dilated);
                 }
-                const float rcp_w = __builtin_amdgcn_rcpf(clip_w);
                 const float dLx_j = (j & 1) ? dLx[gi][j >> 1].y : dLx[gi][j >> 1].x, dLy_j = (j & 1) ? dLy[gi][j >> 1].y : dLy[gi][j >> 1].x;
-                float2v f = (float2v{dLx_j, dLy_j} * half_size) * float2v{rcp_w, rcp_w};
-                const bool own = __builtin_amdgcn_inverse_ballot_w64(m_cov & ~dil);   // contributes to its own pixel
+                const float2v t = float2v{dLx_j, dLy_j} * half_size;
+                const float2v f = t * float2v{rcp_own, rcp_own};
+                const bool own = covered[j] & !dilated;       // contributes to its own pixel
                 fxy[j] += float2v{own ? f.x : 0.f, own ? f.y : 0.f};
-                if (dilated) {  // few lanes: ds_add_f32 into the neighbour's cell
-                    const int step = __builtin_amdgcn_inverse_ballot_w64(hz) ? 1 : -IS;   // +x, or up = the previous row
-                    float* cell = reinterpret_cast<float*>(inbox + (my_cell + j + (__builtin_amdgcn_inverse_ballot_w64(fwd) ? step : -step)));
-                    atomicAdd(cell, f.x);
-                    atomicAdd(cell + 1, f.y);
+                if (dilated) {  // few lanes: ds_add_f32 into the neighbour's cell, with the NEIGHBOUR's clip_w
+                    const float rcp_w = __builtin_amdgcn_rcpf(first ? q1 : q2);
+                    const float2v fn = t * float2v{rcp_w, rcp_w};
+                    const int step = hz ? 1 : -IS;            // +x, or up = the previous row
+                    const bool fwd = first == pos;            // the neighbour taken lies at +x / up
+                    float* cell = reinterpret_cast<float*>(inbox + (my_cell + j + (fwd ? step : -step)));
+                    atomicAdd(cell, fn.x);
+                    atomicAdd(cell + 1, fn.y);
                 }
             }
         }
@@ -731,6 +741,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         gather_positions(fpos_xy, fpos_w, lkey, lb, lf);
         GMARK();  // 6 face loop starts
         face_loop(integral_constant<int, NCH>{}, g, key, covered, fpos_xy, fpos_w, lkey, lb, lf);
+        store_background();
     };
 
     run_pass(integral_constant<int, CSPEC>{}, integral_constant<int, CSPEC == 1 ? 1 : 3>{});

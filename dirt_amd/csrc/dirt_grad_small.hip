@@ -339,6 +339,15 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
         role_base[e] = is_pos ? grad_vertices + (c - NCH == 2 ? 3 : c - NCH) : grad_vertex_colors + c;   // (.z is never written, :228-230)
         role_stride[e] = 4u * (uint32_t)(is_pos ? p.gv_stride : p.gvc_stride);
     }
+    // the lane's products b_k * (g.., fx, fy, fw) of its pixel and b_k * (fx, fy, fw) of its ring cell: loop invariant
+    float prod_own[3][S], prod_ring[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int c = 0; c < S; ++c) prod_own[k][c] = bk[k] * fval[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) prod_ring[k][c] = lb[k] * lf[c];
+    }
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t pend0 = covered ? (uint32_t)f_own : NONE, pend1 = (uint32_t)lkey;
     auto next_face = [&]() {
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
                 r = max(r, (uint32_t)__builtin_amdgcn_mov_dpp((int)r, 0x124 /* row_ror:4 */, 0xF, 0xF, true));
                 r = max(r, (uint32_t)__builtin_amdgcn_mov_dpp((int)r, 0x122 /* row_ror:2 */, 0xF, 0xF, true));
                 r = max(r, (uint32_t)__builtin_amdgcn_mov_dpp((int)r, 0x121 /* row_ror:1 */, 0xF, 0xF, true));
-                rvid[k] = r - 1u;   // (a row without a face this iteration: 0xFFFFFFFF, never used -- its totals are zero)
+                rvid[k] = r != 0u ? r - 1u : 0u;   // (a row without a face this iteration: vertex 0, and `live` keeps it from adding anything)
             }
         }
         int vsel[NROLES];
@@ -378,16 +387,18 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
         for (int e = 0; e < NROLES; ++e) vsel[e] = (int)(role_k[e] == 0 ? rvid[0] : (role_k[e] == 1 ? rvid[1] : rvid[2]));
         pend0 = m0 ? NONE : pend0;
         pend1 = m1 ? NONE : pend1;
+        // (selects of the lane's own products, not products with a zeroed factor: a non-finite grad_pixels / position
+        // factor of a pixel that is NOT of this face must not reach the face's totals -- 0 * NaN -- where the reference adds
+        // a pixel's terms to its own face's vertices only, csrc/rasterise_grad_egl.cu:140,228-230)
         float acc[NR];
 #pragma unroll
         for (int i = NV; i < NR; ++i) acc[i] = 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float bm = m0 ? bk[k] : 0.f, bl = m1 ? lb[k] : 0.f;
 #pragma unroll
-            for (int c = 0; c < S; ++c) acc[k * S + c] = bm * fval[c];
+            for (int c = 0; c < S; ++c) acc[k * S + c] = m0 ? prod_own[k][c] : 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[k * S + NCH + c] = fmaf(bl, lf[c], acc[k * S + NCH + c]);
+            for (int c = 0; c < 3; ++c) acc[k * S + NCH + c] += m1 ? prod_ring[k][c] : 0.f;
         }
         const uint32_t K_next = next_face();
         float d0, d1;
@@ -404,7 +415,7 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
         }
 #pragma unroll
         for (int e = 0; e < NROLES; ++e)
-            if (role_valid[e] && total[e] != 0.f)
+            if (role_valid[e] && live && total[e] != 0.f)
                 asm volatile("global_atomic_add_f32 %0, %1, off" : : "v"(dst[e]), "v"(total[e]) : "memory");
         K = K_next;
     }

@@ -304,3 +304,42 @@ def test_deferred_sample_end_to_end(gpu, oracle):
     parity.grad_close(attributes.grad, want_a, 'grad_vertex_colors', 'vertex attributes', 0)
     _close(view_in.grad, view2.grad, 'view matrix', tol=1e-5)
     _close(light_in.grad, light2.grad, 'light direction', tol=1e-5)
+
+
+def _k5_shader(g, light):
+    """A smooth 16 -> 3 channel per-pixel shader in the manner of samples/deferred.py:58-103: a mask channel, an albedo
+    triple, a normal triple lit by a direction, and an emissive triple."""
+    mask, albedo, normal, emissive = g[..., 0:1], g[..., 4:7], g[..., 7:10], g[..., 10:13]
+    diffuse = torch.relu((normal * light).sum(-1, keepdim=True))
+    return mask * albedo * (0.3 + diffuse) + 0.1 * emissive * g[..., 13:14]
+
+
+def test_k5_through_rasterise_deferred_at_full_size(gpu, oracle):
+    """BASELINE.json config 5 as stated: `rasterise_deferred` (dirt/rasterise_ops.py:180-257, samples/deferred.py:105-117)
+    on the K5 scene -- 2048 x 2048 x 16 G-buffer, 50 000 triangles, 3-channel shader.  Both gradient passes (vertex
+    gradients from filtering the SHADED image, attribute / background gradients from the G-buffer) share the forward's
+    state, and both are compared per element with the oracle composition of _deferred_reference."""
+    s = scenes.config_scene('K5')
+    H, W, C = s['height'], s['width'], s['channels']
+    assert (H, W, C, s['faces'].shape[0]) == (2048, 2048, 16, 50000)
+    bg = torch.from_numpy(s['background']).to(gpu).requires_grad_(True)
+    v = torch.from_numpy(s['vertices']).to(gpu).requires_grad_(True)
+    attrs = torch.from_numpy(s['vertex_colors']).to(gpu).requires_grad_(True)
+    f = torch.from_numpy(s['faces']).to(gpu)
+    light = torch.nn.functional.normalize(torch.tensor([0.4, 0.5, 0.7], device=gpu), dim=0).requires_grad_(True)
+    px = ops.rasterise_deferred(bg, v, attrs, f, _k5_shader, [light])
+    d = torch.from_numpy(np.random.default_rng(11).standard_normal((H, W, 3)).astype(np.float32)).to(gpu)
+    px.backward(d)
+
+    gbuf = oracle.forward(s['background'][None], s['vertices'][None], s['vertex_colors'][None], s['faces'][None])
+    gt = torch.from_numpy(gbuf[0]).to(gpu).requires_grad_(True)
+    l2 = light.detach().clone().requires_grad_(True)
+    shaded = _k5_shader(gt, l2)
+    assert torch.allclose(px, shaded.detach(), atol=1e-6)
+    shaded.backward(d)
+    want_v = oracle.backward(s['vertices'][None], s['faces'][None], shaded.detach().cpu().numpy()[None], d.cpu().numpy()[None])
+    want_a = oracle.backward(s['vertices'][None], s['faces'][None], gbuf, gt.grad.cpu().numpy()[None])
+    parity.grad_close(v.grad, want_v, 'grad_vertices', 'K5 deferred: vertices (from the shaded image)', 0)
+    parity.grad_close(attrs.grad, want_a, 'grad_vertex_colors', 'K5 deferred: attributes (from the G-buffer)', 0)
+    assert np.array_equal(bg.grad.cpu().numpy(), want_a['grad_background'][0]), 'K5 deferred: background attributes'
+    assert torch.allclose(light.grad, l2.grad, rtol=1e-4, atol=1e-3 * float(l2.grad.abs().max()))

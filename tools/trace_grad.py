@@ -22,17 +22,20 @@ for it in range(3):
     torch.cuda.synchronize()
 a = buf.cpu().numpy().reshape(-1, 16)
 a = a[a[:, 0] != 0]   # (the buffer is sized for the larger of the two tilings)
-tt = a[:, :8].astype(np.float64)
+NT = 10 if (a[:, 9] != 0).any() else 8   # (10 timestamps since the segment-merging face loop)
+tt = a[:, :NT].astype(np.float64)
 d = np.diff(tt, axis=1)
 names = ['issue loads + state tile', 'store planes', 'barrier', 'Scharr', 'dilation', 'list + roles', 'face loop']
+if NT == 10:
+    names = names[:6] + ['segments', 'iterations', 'stores + flush']
 print('%s: %d waves; clocks per wave (s_memtime), mean / median / max' % (cfg, len(a)))
 for i, n in enumerate(names):
     print('  %-26s %9.0f %9.0f %9.0f' % (n, d[:, i].mean(), np.median(d[:, i]), d[:, i].max()))
-tot = tt[:, 7] - tt[:, 0]
+tot = tt[:, NT - 1] - tt[:, 0]
 print('  %-26s %9.0f %9.0f %9.0f' % ('total', tot.mean(), np.median(tot), tot.max()))
 print('  dilated pairs listed per wave: mean %.1f max %d;  face-loop iterations per wave: mean %.1f max %d' % (a[:, 12].mean(), a[:, 12].max(), a[:, 13].mean(), a[:, 13].max()))
-print('  face loop clocks per iteration: %.0f' % (d[:, 6].sum() / max(1, a[:, 13].sum())))
-print('  kernel span (first start .. last end, clocks; not comparable across CUs): %d' % (tt[:, 7].max() - tt[:, 0].min()))
+print('  face loop clocks per iteration: %.0f' % (d[:, 7 if NT == 10 else 6].sum() / max(1, a[:, 13].sum())))
+print('  kernel span (first start .. last end, clocks; not comparable across CUs): %d' % (tt[:, NT - 1].max() - tt[:, 0].min()))
 
 w0 = a[:, 14].astype(np.float64); w1 = w0 + (a[:, 15] >> 20).astype(np.float64)
 t0 = w0.min()
@@ -57,7 +60,7 @@ print('    SIMD of the 4 waves of block 0:', simd[0:4])
 it = a[:, 13].astype(np.float64)
 print('  corr(wave total, face-loop iterations) = %.2f;  totals: p50 %.0f p90 %.0f p99 %.0f max %.0f' % (
     np.corrcoef(tot, it)[0, 1], *np.percentile(tot, [50, 90, 99, 100])))
-wg_it = it.reshape(-1, 4).sum(1); wg_end = tt[:, 7].reshape(-1, 4).max(1) - tt[:, 0].reshape(-1, 4).min(1)
+wg_it = it.reshape(-1, 4).sum(1); wg_end = tt[:, NT - 1].reshape(-1, 4).max(1) - tt[:, 0].reshape(-1, 4).min(1)
 print('  per workgroup: corr(duration, iterations) = %.2f' % np.corrcoef(wg_end, wg_it)[0, 1])
 if len(wg_it) == 1024:
     cu_it = wg_it.reshape(4, 256).sum(0); cu_end = wg_end.reshape(4, 256).max(0)
@@ -79,3 +82,12 @@ if len(wg_last) == 1024:
         print('    tile row %d of the XCD band: workgroup end mean %.2f us' % (r, wg_last[row_in_band == r].mean()))
     order = np.argsort(wg_last)[-12:]
     print('    last workgroups (block, tile, end us, iterations):', [(int(x), int(tile[x]), round(float(wg_last[x]), 2), int(wg_it[x])) for x in order])
+
+# phase means by dispatch group (blocks b, b+256, b+512, b+768 share a CU; earlier groups are dispatched first)
+if len(a) == 4096:
+    grp = (np.arange(4096) // 4) // 256
+    st = (w0 - t0) / 100.0
+    print('  by dispatch group (blocks 0-255, 256-511, ...): start us | ' + ' | '.join(names) + ' | total clocks | end us')
+    for gidx in range(4):
+        m = grp == gidx
+        print('    group %d: %5.2f | ' % (gidx, st[m].mean()) + ' | '.join('%6.0f' % d[m, i].mean() for i in range(len(names))) + ' | %6.0f | %5.2f' % (tot[m].mean(), en[m].mean()))
