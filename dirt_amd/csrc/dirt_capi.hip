@@ -193,7 +193,6 @@ dirt::GeomParams geom_params(const Carved& c, const float* vertices, const int32
     g.vertices = vertices; g.faces = faces; g.recs = c.recs; g.boxes = c.boxes; g.cells = c.cells;
     g.entries = c.entries;
     dirt::chunking(F, g.nchunk, g.chunk_faces);
-    g.zero_b = nullptr; g.zero_b_bytes = 0; g.zero_c = nullptr; g.zero_c_bytes = 0;
     g.B = B; g.V = V; g.F = F; g.H = H; g.W = W;
     g.grid = dirt::make_bin_grid(H, W);
     return g;
@@ -207,6 +206,7 @@ dirt::RasterParams raster_params(const Carved& c, const dirt::GeomParams& g, int
     p.background = nullptr; p.vertex_colors = nullptr; p.pixels = nullptr; p.vis = nullptr; p.state_a = nullptr; p.state_b = nullptr;
     p.V = g.V; p.F = g.F; p.H = g.H; p.W = g.W; p.C = C;
     p.grid = g.grid; p.tiles_x = 0; p.tiles_y = 0;
+    p.zero_b = nullptr; p.zero_b_bytes = 0; p.zero_c = nullptr; p.zero_c_bytes = 0;
     return p;
 }
 
@@ -243,17 +243,18 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const Carved c = carved(workspace, w);
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
-    dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
-    if (flags & DIRT_FLAG_KEEP_STATE) {  // pre-clear the backward pass's accumulators (dirt_state_grad_buffers)
-        g.zero_b = c.gv;  g.zero_b_bytes = sizeof(float) * (size_t)B * V * w.acc_stride;
-    }
+    const dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
     {
         Scope sc(prof, SLOT_GEOMETRY, stream);
         HIP_TRY(who, dirt::launch_geometry(g, stream));
     }
     dirt::RasterParams p = raster_params(c, g, C, flags);
     p.background = background; p.vertex_colors = vertex_colors; p.pixels = pixels;
-    if (flags & DIRT_FLAG_KEEP_STATE) { p.state_a = c.state_a; p.state_b = c.state_b; }
+    if (flags & DIRT_FLAG_KEEP_STATE) {
+        p.state_a = c.state_a; p.state_b = c.state_b;
+        // pre-clear the backward pass's accumulators (dirt_state_grad_buffers), a side job of the raster kernel's workgroups
+        p.zero_b = c.gv;  p.zero_b_bytes = sizeof(float) * (size_t)B * V * w.acc_stride;
+    }
     {
         Scope sc(prof, SLOT_RASTER_FWD, stream);
         HIP_TRY(who, dirt::launch_raster(p, B, false, stream));
@@ -332,15 +333,15 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
                                            sizeof(float) * (size_t)B * V * C, stream));
         }
     } else {
-        dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
-        g.zero_b = grad_vertices;      g.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
-        g.zero_c = grad_vertex_colors; g.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
+        const dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
         {
             Scope sc(prof, SLOT_GEOMETRY, stream);
             HIP_TRY(who, dirt::launch_geometry(g, stream));
         }
         dirt::RasterParams rp = raster_params(c, g, C, flags);
         rp.state_a = c.state_a; rp.state_b = c.state_b;
+        rp.zero_b = grad_vertices;      rp.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
+        rp.zero_c = grad_vertex_colors; rp.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
         {
             Scope sc(prof, SLOT_RASTER_VIS, stream);
             HIP_TRY(who, dirt::launch_raster(rp, B, true, stream));

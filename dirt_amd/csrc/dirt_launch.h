@@ -36,10 +36,6 @@ struct GeomParams {
     FaceBox* boxes;         // [B*F]
     BinCell* cells;         // [B][nchunk][MAX_BINS + 1] chunk x bin directory
     BinEntry* entries;      // [B][nchunk][5 * chunk_faces] per-chunk entry segments, sorted by bin
-    void* zero_b;           // optional extra buffers cleared by the same launch (multiples of 16 bytes)
-    size_t zero_b_bytes;
-    void* zero_c;
-    size_t zero_c_bytes;
     int B, V, F, H, W;
     int nchunk, chunk_faces;  // faces are processed in nchunk contiguous chunks per scene
     BinGrid grid;
@@ -60,6 +56,11 @@ struct RasterParams {
     BinGrid grid;
     unsigned flags;              // DIRT_FLAG_TILES_*
     int tiles_x, tiles_y;        // filled by launch_raster
+    void* zero_b;                // optional buffers cleared by the same launch: the backward pass's gradient accumulators
+    size_t zero_b_bytes;         //   (the cudaMemsetAsync x4 of csrc/rasterise_grad_egl.cu:244-250)
+    void* zero_c;
+    size_t zero_c_bytes;
+    unsigned zero_b_per, zero_c_per;   // 16-byte units per workgroup, filled by launch_raster
 };
 
 struct GradParams {

@@ -89,38 +89,22 @@ __global__ __launch_bounds__(STHREADS * NW) void setup_kernel(GeomParams g)
     static_assert(MAX_BINS == 4 * STHREADS, "four bins per lane");
     const int f0 = chunk * g.chunk_faces, f1 = min(g.F, f0 + g.chunk_faces);
     const float* __restrict__ verts = g.vertices + (size_t)ib * g.V * 4;
-    // This thread's first face: its indices, then its vertices, are requested before anything else, and the clearing
-    // below runs while they are on their way (a chunk is one wave, alone on its SIMD: per-wave trace 1900 clocks of
-    // clearing followed by two exposed round trips, before this order).
+    // This thread's first face: its indices, then its vertices, are requested before anything else.  (Rounds 1-3 cleared the
+    // backward pass's gradient accumulators here as a side job: 38 400 16-byte stores over 157 single-wave workgroups,
+    // 2 600 clocks of every wave's 9 200; the raster kernel's 1024 workgroups do it now, one store per 7 threads.)
     const bool have_first = f0 + tid < f1;
     int32_t idx_first[3] = {0, 0, 0};
     float4 vv_first[3];
     if (have_first) face_fetch_indices(g.faces + (g.shared_faces ? (size_t)(f0 + tid) : (size_t)ib * g.F + f0 + tid) * 3, idx_first);
     for (int i = tid; i <= MAX_BINS; i += NT) s_cnt[i] = 0;
     if (have_first) face_fetch_vertices(verts, g.V, idx_first, vv_first);
-    // side job: clear the gradient accumulators of the backward pass (the cudaMemsetAsync x4 of
-    // csrc/rasterise_grad_egl.cu:244-250) so that no separate launch is needed for it
-    {
-        // 16 bytes per store (the buffers are 16-byte aligned and their sizes multiples of 16: [B,V,4] floats and the
-        // 256-byte aligned workspace regions; caller tensors of other sizes get a dword tail)
-        const size_t nthreads = (size_t)gridDim.x * gridDim.y * NT;
-        const size_t gtid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NT + tid;
-        uint4* zb = reinterpret_cast<uint4*>(g.zero_b);
-        uint4* zc = reinterpret_cast<uint4*>(g.zero_c);
-        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-        for (size_t i = gtid; i < g.zero_b_bytes / 16; i += nthreads) zb[i] = z4;
-        for (size_t i = gtid; i < g.zero_c_bytes / 16; i += nthreads) zc[i] = z4;
-        uint32_t* tb = reinterpret_cast<uint32_t*>(g.zero_b) + (g.zero_b_bytes / 16) * 4;
-        uint32_t* tc = reinterpret_cast<uint32_t*>(g.zero_c) + (g.zero_c_bytes / 16) * 4;
-        if (gtid < (g.zero_b_bytes % 16) / 4) tb[gtid] = 0u;
-        if (gtid < (g.zero_c_bytes % 16) / 4) tc[gtid] = 0u;
-    }
     __syncthreads();
     SETUP_MARK();  // 1 cleared, first face requested
 
     // ---- pass 1: set-up + histogram ----
-    FaceBox first_box;  // the box of this thread's first face stays in registers for pass 2
-    first_box.i_min = 32767; first_box.i_max = -32768; first_box.r_min = 32767; first_box.r_max = -32768;
+    // the box of this thread's first face stays in registers for pass 2 (as four scalars: kept as a FaceBox the compiler
+    // left a dead 8-byte store to a stack slot behind, and with it a scratch allocation at every dispatch of this kernel)
+    int fb_i_min = 32767, fb_i_max = -32768, fb_r_min = 32767, fb_r_max = -32768;
     for (int f = f0 + tid; f < f1; f += NT) {
         const size_t n = (size_t)ib * g.F + f;
         FaceRec rec;
@@ -140,7 +124,7 @@ __global__ __launch_bounds__(STHREADS * NW) void setup_kernel(GeomParams g)
             g.recs[n].flags = 0;
             box.i_min = 32767; box.i_max = -32768; box.r_min = 32767; box.r_max = -32768;
         }
-        if (f == f0 + tid) first_box = box;
+        if (f == f0 + tid) { fb_i_min = box.i_min; fb_i_max = box.i_max; fb_r_min = box.r_min; fb_r_max = box.r_max; }
         if (g.chunk_faces > NT) g.boxes[n] = box;  // re-read in pass 2 when a thread owns several faces
     }
     SETUP_MARK();  // 2 pass 1 done (set-up + histogram)
@@ -185,7 +169,8 @@ __global__ __launch_bounds__(STHREADS * NW) void setup_kernel(GeomParams g)
     BinEntry* __restrict__ out = g.entries + ((size_t)ib * g.nchunk + chunk) * (5 * (size_t)g.chunk_faces);
     for (int f = f0 + tid; f < f1; f += NT) {
         BinEntry e;
-        e.box = (f == f0 + tid) ? first_box : g.boxes[(size_t)ib * g.F + f];
+        if (f == f0 + tid) { e.box.i_min = (int16_t)fb_i_min; e.box.i_max = (int16_t)fb_i_max; e.box.r_min = (int16_t)fb_r_min; e.box.r_max = (int16_t)fb_r_max; }
+        else e.box = g.boxes[(size_t)ib * g.F + f];
         if (e.box.i_min > e.box.i_max) continue;  // culled at set-up
         e.face = f; e.pad = 0;
         int bx0, bx1, by0, by1;
@@ -333,6 +318,18 @@ __device__ __forceinline__ void store_state(const RasterParams& p, size_t pix, b
     p.state_b[pix] = has ? encode_bary(b0, b1, b2) : make_float2(-1.f, -1.f);
 }
 
+// One workgroup's share of a buffer to clear: `per` 16-byte units (the buffers are 16-byte aligned: [B,V,4] floats, the
+// 256-byte aligned workspace regions), a dword tail for caller tensors whose size is not a multiple of 16.
+__device__ __forceinline__ void zero_share(void* buf, size_t bytes, unsigned per, unsigned gwg, int tid)
+{
+    const size_t units = bytes / 16;
+    const size_t i0 = (size_t)gwg * per;
+    uint4* q = reinterpret_cast<uint4*>(buf);
+    for (unsigned i = (unsigned)tid; i < per; i += RTHREADS)
+        if (i0 + i < units) q[i0 + i] = make_uint4(0u, 0u, 0u, 0u);
+    if (gwg == 0 && (size_t)tid < (bytes % 16) / 4) reinterpret_cast<uint32_t*>(buf)[units * 4 + tid] = 0u;
+}
+
 // raster_kernel<MODE, NB, CSPEC>: MODE 0 renders (pixels, and the backward pass's state when p.state_a), MODE 1 is the
 // visibility pass (p.vis and / or the state; no colours).  CSPEC = 1, 3, 4: that channel count, vertex colours of the
 // listed candidates staged in LDS; 0: any channel count.
@@ -435,6 +432,12 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
     bool lds_records = true;   // false once a second round has reused the list (dense meshes): records come from memory then
     int n_first = 0;           // candidates listed in the first round
 
+    // side job: this workgroup's share of the buffers the launch clears (the backward pass's gradient accumulators)
+    if ((p.zero_b_bytes | p.zero_c_bytes) != 0) {
+        const unsigned gwg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (p.zero_b_bytes) zero_share(p.zero_b, p.zero_b_bytes, p.zero_b_per, gwg, tid);
+        if (p.zero_c_bytes) zero_share(p.zero_c, p.zero_c_bytes, p.zero_c_per, gwg, tid);
+    }
     TRACE_MARK();  // 1: directory requested
     for (int round = 0;; ++round) {
         if (tid == 0) s_count = 0;
@@ -757,6 +760,11 @@ hipError_t launch_raster(const RasterParams& p_in, int B, bool visibility_only, 
     p.tiles_x = (p.W + tile - 1) / tile;
     p.tiles_y = (p.H + tile - 1) / tile;
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)B);
+    {
+        const size_t nwg = (size_t)grid.x * grid.y;
+        p.zero_b_per = (unsigned)((p.zero_b_bytes / 16 + nwg - 1) / nwg);
+        p.zero_c_per = (unsigned)((p.zero_c_bytes / 16 + nwg - 1) / nwg);
+    }
     const int cspec = visibility_only ? 0 : (p.C == 4 ? 4 : (p.C == 3 ? 3 : (p.C == 1 ? 1 : 0)));
 #define DIRT_LAUNCH_RASTER(NB_)                                                                               \
     do {                                                                                                      \
