@@ -84,6 +84,7 @@ def main():
                          'reported either way (ms_per_step_eager / ms_per_step_graph)')
     ap.add_argument('--flags', type=lambda x: int(x, 0), default=0, help='extra DIRT_FLAG_* bits for every call (kernel-shape experiments)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the short K3-256 / K3-2048 legs')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
     args = ap.parse_args()
 
@@ -211,6 +212,55 @@ def main():
     total_pixels = world * spg * P
     value = total_pixels / (elapsed / args.steps) / 1e6
 
+    # ---- the same K steps between a HIP-event pair ON THE STREAM the kernels are launched on (torch's current
+    #      stream: the wrapper passes torch.cuda.current_stream().cuda_stream to the C ABI), no synchronisation between the
+    #      warm-up and the timed steps, median of five such regions.  The wall-clock figure above (the contract's: barrier +
+    #      synchronize on both sides) also carries the empty-queue ramp of the first steps and the host's wake-up.
+    def event_region(fn, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(min(10, n)):
+            fn()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n          # ms per step
+
+    regions = sorted(event_region(run, args.steps) for _ in range(5))
+    ms_per_step_events = regions[len(regions) // 2]
+
+    # ---- the autograd path: dirt.rasterise_batch(...).backward() with leaf tensors, i.e. what a user of the reference's API
+    #      pays -- the same three kernels plus the two copies that hand back DENSE grad_vertices / grad_vertex_colors
+    #      (the op returns dense tensors: csrc/rasterise_grad_egl.cpp:381-391) and torch's own bookkeeping ----
+    bg_l, v_l, vc_l = (x.clone().requires_grad_(True) for x in (bg, v, vc))
+
+    def autograd_step():
+        bg_l.grad = v_l.grad = vc_l.grad = None
+        ops.rasterise_batch(bg_l, v_l, vc_l, f, H, W, C).backward(g)
+
+    ms_per_step_autograd = sorted(event_region(autograd_step, max(20, min(args.steps, 200))) for _ in range(3))[1]
+    del bg_l, v_l, vc_l
+
+    # ---- the other frame sizes BASELINE.json's north_star asks for (256^2 and 2048^2, same mesh): short legs, one scene ----
+    other_configs = {}
+    if rank == 0 and world == 1 and args.config == 'K3' and not args.no_other_configs:
+        for name in ('K3-256', 'K3-2048'):
+            F2, H2, W2, C2, seed2, lo2, hi2 = scenes.CONFIGS[name]
+            b2 = scenes.batch_scene(F2, H2, W2, C2, [seed2], r_lo=lo2, r_hi=hi2)
+            bg2, v2, vc2, f2, g2 = (t(b2[k]) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels'))
+
+            def step2():
+                px2, st2 = ops._op_rasterise(bg2, v2, vc2, f2, H2, W2, C2, flags=args.flags, keep_state=True)
+                return ops._op_rasterise_grad(v2, f2, px2, g2, H2, W2, C2, flags=args.flags, state=st2)
+
+            ms2 = sorted(event_region(step2, 100) for _ in range(3))[1]
+            by2 = algorithmic_bytes(H2 * W2, b2['vertices'].shape[1], F2, C2)
+            other_configs[name] = {'ms_per_step': ms2, 'value': H2 * W2 / ms2 / 1e3, 'unit': 'Mpixels/s', 'steps': 100,
+                                   'roofline_step_frac': by2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                   'workload': 'rand_mesh F=%d at %dx%dx%d, 1 scene, forward+backward' % (F2, H2, W2, C2)}
+            del bg2, v2, vc2, f2, g2
+
     # ---- N > 1: the same per-GPU workload on rank 0 ALONE (every other rank idles at the barrier), so that the line
     #      carries its own one-GPU reference for exactly this scenes-per-GPU count ----
     scaling_reference = None
@@ -260,11 +310,10 @@ def main():
         torch.cuda.synchronize()
         prof = _lib.profile_read()
         kbytes = kernel_algorithmic_bytes(P, V, F, C)
-        # An event pair around a launch reads ~2 us longer than the kernel runs (the closing event's packet is processed after
-        # the kernel has drained): the raw readings of a step sum to MORE than the step takes.  The excess, shared equally
-        # among the step's launches, is taken off each reading (the step also contains the gaps between kernels, so this
-        # does not over-correct by more than those): the corrected times sum to the eager step and agree with rocprofv3's
-        # kernel trace of the same command within ~3 % (profiles/README.md).
+        # avg_us is the RAW reading of the event pair around a launch.  An event pair reads ~2 us longer than the kernel runs
+        # (the closing event's packet is processed after the kernel has drained), so the raw readings of a step sum to more
+        # than the step takes; `avg_us_corrected` takes that excess, shared equally among the step's launches, off -- an
+        # estimate (it agrees with rocprofv3's kernel trace within ~3 %, profiles/README.md), never used for the roofline.
         raw_us = {name: ms / n * 1e3 for name, (ms, n) in prof.items() if n}
         launches = sum(n for _, n in prof.values()) / args.steps
         eager_step_us = (ms_per_step if not use_graph else calib['eager_ms_per_step']) * 1e3
@@ -273,8 +322,8 @@ def main():
         for name, (ms, n) in prof.items():
             if n:
                 raw = raw_us[name]
-                kernels[name] = {'launches_per_step': n / args.steps, 'avg_us': max(raw - pair_us, 0.0), 'avg_us_event_pair': raw,
-                                 'us_per_step': max(raw - pair_us, 0.0) * n / args.steps}
+                kernels[name] = {'launches_per_step': n / args.steps, 'avg_us': raw, 'avg_us_corrected': max(raw - pair_us, 0.0),
+                                 'us_per_step': raw * n / args.steps}
         dom = max(kernels, key=lambda k: kernels[k]['us_per_step'])
         avg_s = kernels[dom]['avg_us'] * 1e-6
         per_launch = kbytes[dom] * spg
@@ -310,10 +359,12 @@ def main():
                     'frac': achieved / HBM_PEAK_GBPS, 'frac_of_measured_copy_peak': achieved / HBM_COPY_GBPS,
                     'traffic': traffic, 'traffic_source': traffic_source, 'traffic_all_kernels': traffic_all,
                     'algorithmic_bytes_per_launch': per_launch, 'avg_launch_us': kernels[dom]['avg_us'],
-                    'avg_launch_us_with_event_pair': kernels[dom]['avg_us_event_pair'], 'event_pair_us': pair_us,
-                    'timing': 'HIP events recorded by the library around each launch on its stream (DIRT_FLAG_PROFILE), eager steps; '
-                              'event_pair_us = (sum of the raw readings of a step - the eager step time) / launches per step is taken '
-                              'off every reading (agrees with the rocprofv3 kernel trace of the same command within ~3 %: profiles/)'}
+                    'avg_launch_us_corrected': kernels[dom]['avg_us_corrected'], 'event_pair_us': pair_us,
+                    'frac_corrected': per_launch / (kernels[dom]['avg_us_corrected'] * 1e-6) / 1e9 / HBM_PEAK_GBPS if kernels[dom]['avg_us_corrected'] else None,
+                    'timing': 'achieved / frac: the RAW HIP-event reading around each launch on its stream (DIRT_FLAG_PROFILE, eager steps), '
+                              'which includes ~2 us of event-pair overhead -- conservative; *_corrected takes (sum of the raw readings of a '
+                              'step - the eager step time) / launches per step off, which agrees with the rocprofv3 kernel trace of the same '
+                              'command within ~3 % (profiles/)'}
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N == 1) ----
     cpu_baseline = None
@@ -350,6 +401,19 @@ def main():
                         'kind': 'port',
                         'sample': '%d x forward+backward of one %s scene (%dx%dx%d, %d triangles), oracle/dirt_oracle.c with OpenMP'
                                   % (n_it, args.config, H, W, C, F)}
+        # "single-thread and all-core": the same oracle on ONE host thread, two passes
+        oracle.set_num_threads(1)
+        n_1, t_1 = 0, 0.0
+        while t_1 < 3.0 and n_1 < 3:
+            c0 = time.perf_counter()
+            px = oracle.forward(one['background'], one['vertices'], one['vertex_colors'], one['faces'])
+            oracle.backward(one['vertices'], one['faces'], px, one['grad_pixels'])
+            t_1 += time.perf_counter() - c0
+            n_1 += 1
+        oracle.set_num_threads(cores)
+        cpu_baseline['single_thread'] = {'value': n_1 * P / t_1 / 1e6, 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'port',
+                                         'sample': '%d x forward+backward of the same scene on one thread' % n_1}
+        cpu_baseline['host_threads_available'] = avail
         # The one part of the reference that compiles for a CPU -- its gradient kernel assemble_grads + launch_grad_assembly,
         # csrc/rasterise_grad_egl.cu, behind oracle/ref_shim (oracle/_ref, prebuilt: it travels with the snapshot) -- timed
         # beside it: BACKWARD only (the channel groups of dirt/rasterise_ops.py:145-165, surfaces from the oracle's
@@ -393,6 +457,14 @@ def main():
                        'scenes_per_gpu': spg, 'parallelism': 'batch-sharded x%d, no collective' % world + (' (DIRT_BENCH_SHARE_GPU: all ranks on ONE GPU over gloo, control-flow test only)' if share_gpu else ''),
                        'launch': 'one captured hipGraph replayed per step' if use_graph else 'eager (Python wrapper + C ABI per step)'},
             'ranks_seen': ranks_seen,
+            'ms_per_step_events_median': ms_per_step_events,
+            'value_events_median': total_pixels / ms_per_step_events / 1e3,
+            'timing': 'ms_per_step / value: wall clock over the K steps between barrier + synchronize (the contract); '
+                      'ms_per_step_events_median: the same K steps between a HIP-event pair on the launch stream, no synchronisation '
+                      'after the warm-up, median of 5 regions (SURVEY.md 8d); ms_per_step_autograd: dirt.rasterise_batch(...).backward() '
+                      'with leaf tensors and dense gradients, event-timed',
+            'ms_per_step_autograd': ms_per_step_autograd,
+            'other_configs': other_configs,
             'ms_per_step_eager': calib['eager_ms_per_step'], 'ms_per_step_graph': calib['graph_ms_per_step'],
             'launch_calibration': calib,
             'scaling_reference': scaling_reference,

@@ -352,11 +352,24 @@ def _rasterise_grad_multichannel(vertices, faces, pixels, d_loss_by_pixels, sing
     return {'grad_vertices': gv, 'grad_vertex_colors': gvc, 'grad_background': gb}
 
 
-_checked_shaders = set()   # code objects of the shader functions whose graphs have been walked once
+_checked_shaders = collections.OrderedDict()   # shader functions (by code AND by what they close over) whose graph was walked
+_CHECKED_SHADERS_MAX = 256
 
 
 def _shader_key(shader_fn):
-    return getattr(shader_fn, '__code__', None) or getattr(getattr(shader_fn, '__call__', None), '__code__', None) or id(shader_fn)
+    """What identifies a shader for the one-time graph walk: its code object together with the identities of the objects
+    it closes over / is bound to -- two closures of one factory share a code object but not their parameters, and a
+    lambda re-created per call with the same captured tensors need not be walked again."""
+    fn = shader_fn if hasattr(shader_fn, '__code__') else getattr(shader_fn, '__call__', shader_fn)
+    code = getattr(fn, '__code__', None)
+    cells = ()
+    for c in (getattr(fn, '__closure__', None) or ()):
+        try:
+            cells += (id(c.cell_contents),)
+        except ValueError:   # an empty cell
+            cells += (0,)
+    bound = id(getattr(fn, '__self__', None)) if getattr(fn, '__self__', None) is not None else 0
+    return (code if code is not None else id(shader_fn), cells, bound)
 
 
 def _unlisted_leaves(output, listed, limit=2000):
@@ -406,7 +419,10 @@ class _RasteriseDeferred(torch.autograd.Function):
         # (the graph walk is a debugging aid with a host-side cost: done on the first call of each shader function only)
         key = _shader_key(shader_fn)
         stray = [] if key in _checked_shaders else _unlisted_leaves(pixels, [gbuffer_in] + list(extra_in) + list(shader_params))
-        _checked_shaders.add(key)
+        _checked_shaders[key] = True
+        _checked_shaders.move_to_end(key)
+        while len(_checked_shaders) > _CHECKED_SHADERS_MAX:   # bounded: a job that builds shaders as it goes does not grow it
+            _checked_shaders.popitem(last=False)
         if stray:
             import warnings
             warnings.warn('rasterise_deferred: shader_fn uses %d tensor(s) that require grad but are neither '

@@ -67,8 +67,10 @@ extern "C" {
 #define DIRT_FLAG_GRAD_PAIRS 0x2000u /* ... or pairs of blocks share a face (fewer float atomics).  Results agree to
                                         summation order (how the parity tests cover both) */
 #define DIRT_FLAG_GRAD_SMALL 0x4000u /* ... or the small-frame gradient kernel: one pixel per lane on 16x16 tiles
-                                        (channel counts 1, 3, 4; chosen by the library for frames of at most 256 32x32
-                                        tiles with at least 96 faces per tile).  Same results to summation order */
+                                        (channel counts 1, 3, 4; chosen by the library when tiles x scenes of the call --
+                                        32x32 tiles -- are at most 256 and the mesh has at least 96 faces per tile, counted
+                                        over ALL faces of a scene, culled and off-screen ones included).  Same results to
+                                        summation order */
 #define DIRT_FLAG_SHARED_FACES 0x800u /* `faces` is one [F,3] topology shared by all B scenes instead of [B,F,3] (the
                                         TODO of csrc/rasterise_egl.cpp:314).  Same flag on the
                                         forward, visibility and backward calls of one scene batch. */

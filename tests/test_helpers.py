@@ -239,3 +239,29 @@ def test_unlisted_shader_parameters_are_detected():
     assert len(found) == 1 and found[0] is stray_w
     assert _unlisted_leaves(out, [g, listed_w, stray_w]) == []
     assert _unlisted_leaves(torch.ones(3), [g]) == []          # no graph at all
+
+
+def test_shader_key_tells_closures_of_one_factory_apart():
+    """The one-time graph walk of rasterise_deferred is keyed on the shader's code AND on what it closes over: two
+    closures of one factory (same code object, different captured parameters) must each be walked; the same closure
+    again must not."""
+    from dirt_amd.rasterise_ops import _shader_key
+
+    def factory(w):
+        return lambda g: g * w
+
+    wa, wb = torch.ones(3, requires_grad=True), torch.ones(3, requires_grad=True)
+    fa, fb = factory(wa), factory(wb)
+    assert fa.__code__ is fb.__code__
+    assert _shader_key(fa) != _shader_key(fb)
+    assert _shader_key(fa) == _shader_key(fa) == _shader_key(factory(wa))
+
+    class Shader:
+        def __init__(self, w):
+            self.w = w
+
+        def __call__(self, g):
+            return g * self.w
+
+    sa, sb = Shader(wa), Shader(wb)
+    assert _shader_key(sa) != _shader_key(sb) and _shader_key(sa) == _shader_key(sa)

@@ -14,7 +14,7 @@ mkdir -p gpurun_out
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print(d['config']['workload'][:8], 'step %.1f us' % (d['ms_per_step'] * 1e3), {k: round(v['avg_us'], 1) for k, v in d['kernels'].items()})
+        d = json.loads(l); print(d['config']['workload'][:8], 'step %.1f us' % (d['ms_per_step'] * 1e3), {k: round(v.get('avg_us_corrected', v['avg_us']), 1) for k, v in d['kernels'].items()})
     elif 'rror' in l: print(l.rstrip())"
   done
 } > gpurun_out/t.log 2>&1

@@ -9,7 +9,7 @@ for v in "$@"; do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print('%-8s' % '$v', d['config']['workload'][:8], 'step %.1f us' % (d['ms_per_step'] * 1e3), {k: round(v['avg_us'], 1) for k, v in d['kernels'].items()})
+        d = json.loads(l); print('%-8s' % '$v', d['config']['workload'][:8], 'step %.1f us' % (d['ms_per_step'] * 1e3), {k: round(v.get('avg_us_corrected', v['avg_us']), 1) for k, v in d['kernels'].items()})
     elif 'rror' in l: print(l.rstrip())"
   done
 done 2>&1 | tee -a gpurun_out/time_libs.log

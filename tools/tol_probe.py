@@ -31,6 +31,7 @@ def probe(name, s, flags=0):
 probe('K3', scenes.config_scene('K3'))
 probe('K3-256', scenes.config_scene('K3-256'))
 probe('K3-2048', scenes.config_scene('K3-2048'))
+probe('K5', scenes.config_scene('K5'))
 for H, W, C, seed, n in ((96, 80, 4, 1, 200), (70, 50, 3, 2, 1200), (33, 65, 1, 3, 400)):
     probe('hostile %d' % seed, scenes.hostile_scene(H, W, C, seed, n))
 probe('tiny tris', scenes.rand_scene(3000, 256, 256, 4, 8, 0.005, 0.04))
