@@ -443,40 +443,64 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
         if (tid == 0) s_count = 0;
         __syncthreads();
         TRACE_MARK();  // 2: cleared, barrier
-        // ---- scan: this thread's runs, four entries per trip ----
+        // ---- scan: this thread's runs, four entries per trip.  The four box tests of a trip are evaluated together and the
+        //      trip's hits of the whole wave claim their list slots with ONE wave-aggregated LDS atomic (rounds 1-3: one per
+        //      entry, i.e. four dependent LDS round trips per trip behind nested divergent branches) ----
         bool full = false;
         uint32_t touch = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             while (run_pos[k] < run_count[k] && !full) {
                 BinEntry en[4];
+                const uint32_t left = run_count[k] - run_pos[k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) en[i] = scene_entries[run_base[k] + run_pos[k] + min((uint32_t)i, left - 1u)];
+                bool hit[4];
+                unsigned long long hm[4];
+                uint32_t before = 0, off[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const uint32_t e = min(run_pos[k] + i, run_count[k] - 1);
-                    en[i] = scene_entries[run_base[k] + e];
+                    const FaceBox box = en[i].box;
+                    hit[i] = ((uint32_t)i < left) & (box.i_min <= tx1) & (box.i_max >= tx0) & (box.r_min <= tr1) & (box.r_max >= tr0);
+                    hm[i] = __builtin_amdgcn_ballot_w64(hit[i]);
+                    off[i] = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm[i], 0u));
+                    before += (uint32_t)__popcll(hm[i]);
+                }
+                uint32_t base = 0;
+                if (before != 0u) {   // (wave-uniform among the lanes of this trip)
+                    const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+                    if ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0u)) == 0)
+                        base = atomicAdd(&s_count, before);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                }
+                uint32_t consumed = min(4u, left);
+#pragma unroll
+                for (int i = 3; i >= 0; --i) {
+                    const uint32_t slot = base + off[i];
+                    if (hit[i] && slot >= (uint32_t)LIST_CAP) { consumed = (uint32_t)i; full = true; }   // not consumed: next round
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (run_pos[k] >= run_count[k] || full) break;
-                    const FaceBox box = en[i].box;
-                    if (box.i_min <= tx1 && box.i_max >= tx0 && box.r_min <= tr1 && box.r_max >= tr0) {
-                        const uint32_t slot = atomicAdd(&s_count, 1u);
-                        if (slot >= (uint32_t)LIST_CAP) { full = true; break; }   // not consumed: next round
+                    const uint32_t slot = base + off[i];
+                    if (hit[i] && slot < (uint32_t)LIST_CAP) {
+                        const FaceBox box = en[i].box;
                         const int bx0 = max(box.i_min - tx0, 0) >> 3, bx1 = min(box.i_max - tx0, TILE - 1) >> 3;
                         const int by0 = max(box.r_min - tr0, 0) >> 3, by1 = min(box.r_max - tr0, TILE - 1) >> 3;
                         const uint32_t rowbits = ((2u << bx1) - (1u << bx0)) & ((1u << BT) - 1u);
-                        uint32_t mask = 0;
-                        for (int by = by0; by <= by1; ++by) mask |= rowbits << (BT * by);
+                        // rows by0 .. by1 of the mask get `rowbits`: one multiplication by the rows' unit bits (no loop, no
+                        // carries: rowbits < 2^BT)
+                        constexpr uint32_t UNIT = BT == 4 ? 0x1111u : 0x5u;   // bit BT * by of every block row
+                        const uint32_t rows = UNIT & ((2u << (BT * by1 + BT - 1)) - (1u << (BT * by0)));
                         s_face[slot] = en[i].face;
-                        s_mask[slot] = (uint16_t)mask;
+                        s_mask[slot] = (uint16_t)(rowbits * rows);
                         // the staging pass reads this face's set-up record (one 128-byte line, written by another XCD's
                         // set-up workgroup) after the list barrier: touch it now, so that it is on its way to this
                         // XCD's L2 while the list is still being built.  The loaded word is never used; `touch` stays
                         // live until the wait below, so that its register is not reused while loads are in flight.
                         asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(recs + en[i].face));
                     }
-                    ++run_pos[k];
                 }
+                run_pos[k] += consumed;
             }
         }
         TRACE_MARK();  // 3: appended
