@@ -7,7 +7,7 @@
 // left); the lane keeps one of the two values, sends the other to its partner and adds what it receives, so registers
 // halve while lanes specialise.  Lane bits 3 and 2 select DPP BANKS (groups of four lanes), so those levels are two
 // bank-masked v_add_f32_dpp per pair and no selects (inline assembly: the masked form has no builtin); bits 1 and 0 are
-// quad permutations (two selects and one DPP add per pair).  N = 24: 24 + 12 + 9 + 4 = 49 instructions for the totals
+// quad permutations (two selects and one DPP add per pair).  N = 24: 24 + 12 + 9 + 4 = 49 instructions (+ 4 s_nop) for the totals
 // of 24 values x 4 rows; a plain DPP row sum of every value would be 96 + the selects.
 //
 // Where the totals end up (row_value_of_lane): with b_k = bit k of the lane,
@@ -33,28 +33,189 @@ __device__ __forceinline__ float pack_pair(float lo, float hi, bool upper)
     return keep + dpp_mov<CTRL>(send);
 }
 
-// The levels whose "upper" lanes are whole DPP banks.  A DPP operand written by the preceding VALU instruction needs
-// two wait states: the leading s_nop.
+// One butterfly level whose "upper" lanes are whole DPP banks, for NP pairs (lo[i], hi[i]) at once, IN PLACE in lo[]: a single
+// asm block, so that the wait states a DPP operand needs behind the VALU instruction that wrote it (two) are paid once
+// per level -- one leading s_nop; inside the block every source was written at least two instructions earlier -- and not
+// once per pair (rounds 2-3: 18 s_nop per reduction, 154 per wave at K3).  The trailing s_nop covers whatever DPP
+// instruction the compiler places behind the block (it does not look inside inline assembly).
 // bit 3 (lanes 8-15 of a row = banks 2, 3): lo + partner's lo everywhere, then hi + partner's hi in the upper banks.
-__device__ __forceinline__ float pack_pair_bit3(float lo, float hi)
-{
-    float r;
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
-        : "=&v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
 // bit 2 (banks 1, 3 are the upper lanes): banks 0, 2 take lo + lo of the lane four above (row_shl:4), banks 1, 3 take
 // hi + hi of the lane four below (row_shr:4).
-__device__ __forceinline__ float pack_pair_bit2(float lo, float hi)
+__device__ __forceinline__ void level_bit3(float (&lo)[12], const float (&hi)[12])
 {
-    float r;
     asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
-        : "=&v"(r) : "v"(lo), "v"(hi));
-    return r;
+            "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %2, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %3, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %4, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %5, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %6, %18, %18 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %7, %19, %19 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %8, %20, %20 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %9, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %9, %21, %21 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %10, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %10, %22, %22 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %11, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %11, %23, %23 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "s_nop 1"
+        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]), "+v"(lo[8]), "+v"(lo[9]), "+v"(lo[10]), "+v"(lo[11])
+        : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]), "v"(hi[8]), "v"(hi[9]), "v"(hi[10]), "v"(hi[11]));
+}
+__device__ __forceinline__ void level_bit3(float (&lo)[8], const float (&hi)[8])
+{
+    asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "s_nop 1"
+        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7])
+        : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]));
+}
+__device__ __forceinline__ void level_bit3(float (&lo)[6], const float (&hi)[6])
+{
+    asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %2, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %3, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %4, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %5, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "s_nop 1"
+        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5])
+        : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]));
+}
+__device__ __forceinline__ void level_bit3(float (&lo)[4], const float (&hi)[4])
+{
+    asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "s_nop 1"
+        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3])
+        : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
+}
+__device__ __forceinline__ void level_bit2(float (&lo)[12], const float (&hi)[12])
+{
+    asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %1, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %2, %14, %14 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %3, %15, %15 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %4, %16, %16 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %5, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %5, %17, %17 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %6, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %6, %18, %18 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %7, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %7, %19, %19 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %8, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %8, %20, %20 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %9, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %9, %21, %21 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %10, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %10, %22, %22 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %11, %11, %11 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %11, %23, %23 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "s_nop 1"
+        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]), "+v"(lo[8]), "+v"(lo[9]), "+v"(lo[10]), "+v"(lo[11])
+        : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]), "v"(hi[8]), "v"(hi[9]), "v"(hi[10]), "v"(hi[11]));
+}
+__device__ __forceinline__ void level_bit2(float (&lo)[8], const float (&hi)[8])
+{
+    asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %1, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %2, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %3, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %4, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %5, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %5, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %6, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %6, %14, %14 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %7, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %7, %15, %15 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "s_nop 1"
+        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7])
+        : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]));
+}
+__device__ __forceinline__ void level_bit2(float (&lo)[6], const float (&hi)[6])
+{
+    asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %1, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %2, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %3, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %4, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %5, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %5, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "s_nop 1"
+        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5])
+        : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]));
+}
+__device__ __forceinline__ void level_bit2(float (&lo)[4], const float (&hi)[4])
+{
+    asm("s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %2, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %3, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "s_nop 1"
+        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3])
+        : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
 }
 
 template <int N>
@@ -63,11 +224,13 @@ __device__ __forceinline__ void row_reduce_scatter(const float* val, int lane, f
     static_assert(N == 16 || N == 24, "16 or 24 values");
     constexpr int QUAD_XOR2 = 0x4E /* [2,3,0,1] */, QUAD_XOR1 = 0xB1 /* [1,0,3,2] */;
     const bool u1 = (lane & 2) != 0, u0 = (lane & 1) != 0;
-    float a[N / 2], b[N / 4], c[N / 8];
+    float a[N / 2], ah[N / 2], b[N / 4], bh[N / 4], c[N / 8];
 #pragma unroll
-    for (int i = 0; i < N / 2; ++i) a[i] = pack_pair_bit3(val[i], val[i + N / 2]);
+    for (int i = 0; i < N / 2; ++i) { a[i] = val[i]; ah[i] = val[i + N / 2]; }
+    level_bit3(a, ah);
 #pragma unroll
-    for (int i = 0; i < N / 4; ++i) b[i] = pack_pair_bit2(a[i], a[i + N / 4]);
+    for (int i = 0; i < N / 4; ++i) { b[i] = a[i]; bh[i] = a[i + N / 4]; }
+    level_bit2(b, bh);
 #pragma unroll
     for (int i = 0; i < N / 8; ++i) c[i] = pack_pair<QUAD_XOR2>(b[i], b[i + N / 8], u1);
     d0 = pack_pair<QUAD_XOR1>(c[0], c[1], u0);
