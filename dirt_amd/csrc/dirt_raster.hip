@@ -264,12 +264,13 @@ __device__ __noinline__ bool covered_exact(const FaceRec* __restrict__ rec, doub
 //             nearest even, like rint), and the bit patterns of non-negative doubles order like the numbers while every
 //             negative one has the top bit set (q is never -0: its constant term fma(zC, S, S) cannot round to -0);
 //   update  : GL_LESS against the stored depth; equal depth keeps the lower face index, which is what drawing the faces
-//             in index order does (csrc/rasterise_egl.cpp:373-379).  Bitwise, not short-circuit, operators: one
-//             predicated update instead of nested divergent branches.
+//             in index order does (csrc/rasterise_egl.cpp:373-379): both as one unsigned compare of the 64-bit key
+//             (z24 << 32 | face).  The stored key starts as (Z24_CLEAR << 32 | 0): no fragment at the cleared depth is
+//             ever less.  Bitwise, not short-circuit, operators: one predicated update instead of nested divergent branches.
 template <int NB>
 __device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec* __restrict__ recs, int ci, uint32_t m4, const float* dx,
-                                                 const float* dy, const double* px, const double* py, uint32_t* zbest,
-                                                 int32_t* fbest, int* cbest)
+                                                 const float* dy, const double* px, const double* py, unsigned long long* best,
+                                                 int* cbest)
 {
 #pragma unroll
     for (int by = 0; by < NB; ++by) {
@@ -299,11 +300,12 @@ __device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec
             const double q = fma(t.zp[0], px[bx], qrow);
             const uint32_t z24 = (uint32_t)__double_as_longlong(q + 4503599627370496.0);
             const unsigned long long in_range_m = __builtin_amdgcn_ballot_w64((unsigned long long)__double_as_longlong(q) <= 0x416FFFFFE0000000ull);   // 0 <= q <= 16777215
-            const unsigned long long wins_m = cov_m & in_range_m &
-                (__builtin_amdgcn_ballot_w64(z24 < zbest[k]) | (__builtin_amdgcn_ballot_w64(z24 == zbest[k]) & __builtin_amdgcn_ballot_w64(t.face < fbest[k])));
+            // (z24, face) as ONE 64-bit key, z24 in the high word: GL_LESS and "equal depth keeps the lower face index" are a
+            // single unsigned 64-bit compare (rounds 1-3: three 32-bit compares and their scalar combination per block)
+            const unsigned long long key = ((unsigned long long)z24 << 32) | (unsigned long long)(uint32_t)t.face;
+            const unsigned long long wins_m = cov_m & in_range_m & __builtin_amdgcn_ballot_w64(key < best[k]);
             const bool wins = __builtin_amdgcn_inverse_ballot_w64(wins_m);
-            zbest[k] = wins ? z24 : zbest[k];
-            fbest[k] = wins ? t.face : fbest[k];
+            best[k] = wins ? key : best[k];
             cbest[k] = wins ? ci : cbest[k];
         }
     }
@@ -424,11 +426,10 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
     }
     const float wf = (float)p.W, hf = (float)p.H;
 
-    uint32_t zbest[PPL];
-    int32_t fbest[PPL];
+    unsigned long long best[PPL];   // (z24 << 32 | face) of the front-most fragment so far
     int cbest[PPL];   // the winner's position in the list (its record is in LDS when < SHADE_CAP and lds_records)
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) { zbest[k] = Z24_CLEAR; fbest[k] = -1; cbest[k] = SHADE_CAP; }  // -1: a tie with the cleared depth never wins
+    for (int k = 0; k < PPL; ++k) { best[k] = (unsigned long long)Z24_CLEAR << 32; cbest[k] = SHADE_CAP; }  // a tie with the cleared depth never wins
     bool lds_records = true;   // false once a second round has reused the list (dense meshes): records come from memory then
     int n_first = 0;           // candidates listed in the first round
 
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
                     m &= m - 1;
                     const TileRec t = s_rec[k];
                     const uint32_t m4 = (uint32_t)__builtin_amdgcn_readlane((int)mym4, k);
-                    raster_candidate<NB>(t, recs, round == 0 ? cb + k : SHADE_CAP, m4, dxl, dyl, px, py, zbest, fbest, cbest);
+                    raster_candidate<NB>(t, recs, round == 0 ? cb + k : SHADE_CAP, m4, dxl, dyl, px, py, best, cbest);
                     TRACE_CNT();
                 }
             }
@@ -575,6 +576,9 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
     }
 
     TRACE_MARK();  // 5: candidates done (one round)
+    int32_t fbest[PPL];   // the front-most face per pixel, -1: none (nothing was less than the cleared depth)
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) fbest[k] = (uint32_t)(best[k] >> 32) != Z24_CLEAR ? (int32_t)(uint32_t)best[k] : -1;
 
     // Many-channel images (C = 8, 12, 16): the shading pass would gather 3 x C floats per PIXEL from memory (K5: 0.8 GB per
     // frame through the L2); instead the workgroup copies the colours of its first QCAP candidates' vertices into LDS
