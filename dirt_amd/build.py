@@ -37,17 +37,44 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source into one shared library.  Raises on failure."""
-    if not force and not needs_build():
+# per-source flags.  dirt_grad.hip: the SLP vectoriser turns two of the four per-pixel barycentric triples into
+# <2 x float> + float stores to a stack slot that is never promoted back to registers (scratch memory + a 3 KB LDS
+# "promoted alloca" in the 1- and 3-channel instantiations); its packed arithmetic is written by hand anyway.
+PER_SOURCE_FLAGS = {'dirt_grad.hip': ['-fno-slp-vectorize']}
+OBJ_DIR = os.path.join(_HERE, 'csrc', '.obj')
+
+
+def build_library(force=False, verbose=False, extra_flags=(), out=None):
+    """Compile every HIP source (one hipcc -c each, in parallel) and link them into one shared library.  Raises on failure.
+    `out`: another path for the library (instrumented / experimental builds under tools/_bin: tools/variants.sh)."""
+    if out is None and not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB_PATH]
+    lib_path = out or LIB_PATH
+    obj_dir = OBJ_DIR if out is None else os.path.join(OBJ_DIR, os.path.basename(out))
+    os.makedirs(obj_dir, exist_ok=True)
+    compile_flags = [f for f in HIPCC_FLAGS if f != '-shared']
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(obj_dir, src + '.o')
+        cmd = [hipcc_path()] + compile_flags + PER_SOURCE_FLAGS.get(src, []) + list(extra_flags) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        procs.append((cmd, obj, subprocess.Popen(cmd)))
+    objs = []
+    for cmd, obj, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        objs.append(obj)
+    link = [hipcc_path(), '--offload-arch=gfx950', '-fPIC', '-shared'] + objs + ['-o', lib_path]
     if verbose:
-        print(' '.join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    return LIB_PATH
+        print(' '.join(link), file=sys.stderr)
+    subprocess.check_call(link)
+    return lib_path
 
 
 if __name__ == '__main__':
-    build_library(force='--force' in sys.argv, verbose=True)
-    print(LIB_PATH)
+    # python -m dirt_amd.build [--force] [--out path.so] [--flags "-DX=1 ..."]
+    argv = sys.argv[1:]
+    out_path = argv[argv.index('--out') + 1] if '--out' in argv else None
+    flags = argv[argv.index('--flags') + 1].split() if '--flags' in argv else []
+    print(build_library(force='--force' in argv, verbose='--quiet' not in argv, extra_flags=flags, out=out_path))

@@ -319,8 +319,42 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         // pending faces: the keys of this lane's pixels / ring cells not yet added (NONE: none or done; "no face" is -1 = NONE)
         constexpr uint32_t NONE = 0xFFFFFFFFu;
         uint32_t pend[6];
+        // ---- non-finite factors (a NaN / Inf in grad_pixels, in `pixels` through the Scharr filter, a degenerate clip_w).
+        //      The loop below multiplies every pixel's factors by a barycentric that is ZEROED where the pixel is not of the
+        //      row's face: 0 * NaN would carry one pixel's NaN into every face of its 16 x 8 half region, where the reference
+        //      adds a pixel's terms to the vertices of its own face only (:140,228-230).  Such a pixel (rare; a sum of
+        //      finite factors that overflows is treated alike) adds its 3 (NCHV + 3) products itself -- the reference's own
+        //      atomics, term for term -- and leaves the loop: factors zeroed, face struck off. ----
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pend[j] = (uint32_t)key[j];
+        for (int j = 0; j < 4; ++j) {
+            float2v t = fp[j][0];
+#pragma unroll
+            for (int h = 1; h < HP; ++h) t += fp[j][h];
+            const float u = (t.x + t.y) + ((bk[j][0] + bk[j][1]) + bk[j][2]);   // non-finite iff a factor is, or the sum overflows
+            const bool bad = !__builtin_isfinite(u);
+            pend[j] = bad ? NONE : (uint32_t)key[j];
+            if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {   // wave-uniform: not taken on finite data
+                if (bad) {
+                    if (key[j] != -1) {
+                        const uint32_t fo = (uint32_t)key[j] * 12u;
+                        const int32_t vk[3] = {ld_off<int32_t>(faces, fo), ld_off<int32_t>(faces, fo + 4u), ld_off<int32_t>(faces, fo + 8u)};
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+#pragma unroll
+                            for (int c = 0; c < S; ++c) {
+                                if (!(c < NCHV || c == IX || c == IY || c == IW) || (STRIDED && NCHV == 4 && !single_on && c == 3)) continue;
+                                const float val = bk[j][k] * ((c & 1) ? fp[j][c / 2].y : fp[j][c / 2].x);
+                                float* dstp = c >= NCHV && (c == IX || c == IY || c == IW)
+                                    ? reinterpret_cast<float*>(reinterpret_cast<char*>(grad_vertices) + (size_t)((uint32_t)vk[k] * gv_row_bytes)) + (c == IW ? 3 : c - IX)
+                                    : reinterpret_cast<float*>(reinterpret_cast<char*>(grad_vertex_colors) + (size_t)((uint32_t)vk[k] * gvc_row_bytes)) + c;
+                                atomicAdd(dstp, val);
+                            }
+                    }
+#pragma unroll
+                    for (int h = 0; h < HP; ++h) fp[j][h] = float2v{0.f, 0.f};
+                }
+            }
+        }
         pend[4] = (uint32_t)lkey[0]; pend[5] = (uint32_t)lkey[1];
         // the row's next face: the smallest pending key of its 16 lanes (an all-lanes minimum by four DPP rotations)
         auto next_face = [&]() {
@@ -454,6 +488,17 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                     const float ndc_x = ((float)px + 0.5f) * p.two_over_w - 1.f;
                     const float ndc_y = ((float)(H - 1 - py) + 0.5f) * p.two_over_h - 1.f;
                     lf[e][0] = v.x; lf[e][1] = v.y; lf[e][2] = -(v.x * ndc_x + v.y * ndc_y);
+                    if (!__builtin_isfinite((v.x + v.y) + ((lb[e][0] + lb[e][1]) + lb[e][2]))) {   // (see the face loop: non-finite factors)
+                        const uint32_t fo = (uint32_t)lkey[e] * 12u;
+                        const int32_t vk[3] = {ld_off<int32_t>(faces, fo), ld_off<int32_t>(faces, fo + 4u), ld_off<int32_t>(faces, fo + 8u)};
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            float* row = reinterpret_cast<float*>(reinterpret_cast<char*>(grad_vertices) + (size_t)((uint32_t)vk[k] * gv_row_bytes));
+                            atomicAdd(row + 0, lb[e][k] * lf[e][0]); atomicAdd(row + 1, lb[e][k] * lf[e][1]); atomicAdd(row + 3, lb[e][k] * lf[e][2]);
+                        }
+                        lkey[e] = -1;
+                        lb[e][0] = 0.f; lb[e][1] = 0.f; lb[e][2] = 0.f; lf[e][0] = 0.f; lf[e][1] = 0.f; lf[e][2] = 0.f;
+                    }
                 }
             }
         }

@@ -411,3 +411,36 @@ def test_misaligned_views_are_accepted(gpu, oracle):
     assert np.array_equal(bg.grad.cpu().numpy(), ow['grad_background'])
     _assert_grad_close(v.grad.cpu().numpy(), ow, 'grad_vertices', 'gv')
     _assert_grad_close(vc.grad.cpu().numpy(), ow, 'grad_vertex_colors', 'gvc')
+
+
+@pytest.mark.parametrize('C', [1, 3, 4, 5])
+@pytest.mark.parametrize('shape', [pytest.param(0x2000, id='pairs'), pytest.param(0x1000, id='rows'), pytest.param(0x4000, id='px1')])
+def test_non_finite_grad_pixels_stay_with_their_own_face(gpu, oracle, C, shape):
+    """The reference adds a pixel's terms to the vertices of that pixel's face only (csrc/rasterise_grad_egl.cu:140,228-230):
+    a NaN / Inf in grad_pixels makes exactly those vertices' gradients non-finite.  The wave-level reductions here
+    multiply by zeroed factors where a pixel is not of the face at hand -- 0 * NaN -- so non-finite pixels take a path of
+    their own (dirt_grad.hip: "non-finite factors"; dirt_grad_small.hip selects products).  Every gradient element must
+    be non-finite exactly where the oracle's is, and within the tolerance elsewhere; covered, uncovered, border and
+    dilated pixels are hit."""
+    H, W = 48, 80
+    s = scenes.rand_scene(70, H, W, C, 23, 0.05, 0.25)
+    g = s['grad_pixels'].copy()
+    rng = np.random.default_rng(5)
+    for n, val in enumerate([np.nan, np.inf, -np.inf, np.nan, np.inf, np.nan, -np.inf, np.nan]):
+        y, x = (0, 3) if n == 0 else (int(rng.integers(0, H)), int(rng.integers(0, W)))
+        g[y, x, int(rng.integers(0, C))] = val
+    g[17, 40, :] = np.nan          # every channel of one pixel
+    b = {k: s[k][None] for k in ('background', 'vertices', 'vertex_colors', 'faces')}
+    b['grad_pixels'] = g[None]
+    want = oracle.forward(b['background'], b['vertices'], b['vertex_colors'], b['faces'])
+    ow = oracle.backward(b['vertices'], b['faces'], want, b['grad_pixels'])
+    assert not np.isfinite(ow['grad_vertices']).all() and not np.isfinite(ow['grad_vertex_colors']).all()
+    assert np.isfinite(ow['grad_vertices']).mean() > 0.5            # ... and most of the mesh stays finite
+    d = {k: _t(b[k], gpu) for k in b}
+    px, state = ops._op_rasterise(d['background'], d['vertices'], d['vertex_colors'], d['faces'], H, W, C, keep_state=True)
+    if C == 5 and shape == 0x4000:
+        pytest.skip('the one-pixel-per-lane kernel takes 1, 3 or 4 channels')
+    for st in (state, None):
+        gb, gv, gvc, _ = ops._op_rasterise_grad(d['vertices'], d['faces'], px, d['grad_pixels'], H, W, C, flags=shape, state=st)
+        assert np.array_equal(gb.cpu().numpy().view(np.uint32), ow['grad_background'].view(np.uint32)), 'grad_background'
+        parity.grads_close(gv, gvc, ow, 'non-finite grad_pixels, C=%d' % C)
