@@ -226,4 +226,16 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles)
     return x * q + min(x, rem) + j;
 }
 
+// tile -> (column, row) of the tile grid without an integer division: q = (tile * magic) >> 32 with
+// magic = floor(2^32 / tiles_x) + 1 is exact for tile * tiles_x < 2^32 (tiles: at most 2^18, tiles_x: at most 2^9); the
+// launcher computes the magic number (tile_magic), the kernels pay one s_mul_hi_u32 instead of the ~25 scalar
+// instructions of a division by a run-time value at the head of every wave.
+// (tiles_x == 1 has no 32-bit magic number -- 2^32 + 1 -- and is marked by 0: the row is the tile index itself.)
+inline uint32_t tile_magic(int tiles_x) { return tiles_x <= 1 ? 0u : (uint32_t)(0x100000000ull / (uint32_t)tiles_x) + 1u; }
+__device__ __forceinline__ void tile_xy(int tile, int tiles_x, uint32_t magic, int& tx, int& ty)
+{
+    ty = magic ? (int)__umulhi((uint32_t)tile, magic) : tile;
+    tx = tile - ty * tiles_x;
+}
+
 }  // namespace dirt

@@ -137,7 +137,9 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         single_on = CSPEC != 4 || item - tile * p.npasses == p.npasses - 1;
     }
     const bool aligned16 = (!STRIDED && CSPEC == 4) ? true : (p.pixels_aligned16 != 0 && (cbase & 3) == 0);
-    const int x0 = (tile % p.tiles_x) * GT, y0 = (tile / p.tiles_x) * GT;
+    int tile_col, tile_row;
+    tile_xy(tile, p.tiles_x, p.tiles_x_magic, tile_col, tile_row);
+    const int x0 = tile_col * GT, y0 = tile_row * GT;
 
     // Wave-uniform bases at the first staged row of the tile (row0), so that every per-lane address is a small
     // non-negative 32-bit byte offset: (row - row0) * W + column, times the element size.
@@ -807,6 +809,7 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     GradParams p = p_in;
     p.tiles_x = (p.W + GT - 1) / GT;
     p.tiles_y = (p.H + GT - 1) / GT;
+    p.tiles_x_magic = tile_magic(p.tiles_x);
     p.two_over_w = 2.f / (float)p.W; p.two_over_h = 2.f / (float)p.H;   // (IEEE divisions, as the kernel's own would be)
     p.pixels_aligned16 = ((reinterpret_cast<uintptr_t>(p.pixels) | reinterpret_cast<uintptr_t>(p.grad_pixels) |
                            reinterpret_cast<uintptr_t>(p.grad_background)) & 15u) == 0 ? 1 : 0;

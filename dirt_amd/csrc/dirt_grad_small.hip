@@ -87,7 +87,9 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
     const int H = p.H, W = p.W;
     constexpr int C = CSPEC;
     const int tile = xcd_tile((int)blockIdx.x, p.tiles_x * p.tiles_y);
-    const int x0 = (tile % p.tiles_x) * ST, y0 = (tile / p.tiles_x) * ST;
+    int tile_col, tile_row;
+    tile_xy(tile, p.tiles_x, p.tiles_x_magic, tile_col, tile_row);
+    const int x0 = tile_col * ST, y0 = tile_row * ST;
     const size_t frame = (size_t)H * W;
     const float2* __restrict__ state_a = p.state_a + (size_t)iib * frame;
     const float2* __restrict__ state_b = p.state_b + (size_t)iib * frame;
@@ -435,6 +437,7 @@ hipError_t launch_grad_small(const GradParams& p, hipStream_t stream)
     GradParams q = p;
     q.tiles_x = (p.W + ST - 1) / ST;
     q.tiles_y = (p.H + ST - 1) / ST;
+    q.tiles_x_magic = tile_magic(q.tiles_x);
     const dim3 grid((unsigned)(q.tiles_x * q.tiles_y), (unsigned)p.B), block(256);
 #define DIRT_LAUNCH_SMALL(C_)                                                                        \
     do {                                                                                             \

@@ -56,6 +56,7 @@ struct RasterParams {
     BinGrid grid;
     unsigned flags;              // DIRT_FLAG_TILES_*
     int tiles_x, tiles_y;        // filled by launch_raster
+    uint32_t tiles_x_magic;      // tile_magic(tiles_x), filled by launch_raster
     void* zero_b;                // optional buffers cleared by the same launch: the backward pass's gradient accumulators
     size_t zero_b_bytes;         //   (the cudaMemsetAsync x4 of csrc/rasterise_grad_egl.cu:244-250)
     void* zero_c;
@@ -79,6 +80,7 @@ struct GradParams {
     int B, V, F, H, W, C;
     unsigned flags;
     int tiles_x, tiles_y;      // filled by launch_grad
+    uint32_t tiles_x_magic;    // tile_magic(tiles_x), filled by launch_grad
     int pixels_aligned16;      // the [B,H,W,C] tensors may be accessed with 16-byte loads / stores, filled by launch_grad
     int c_first, npasses;      // the launch's channel passes (see grad_kernel<CSPEC, STRIDED>), filled by launch_grad
     float two_over_w, two_over_h;  // 2 / W, 2 / H (pixel -> NDC), filled by launch_grad

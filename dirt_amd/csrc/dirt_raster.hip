@@ -386,8 +386,9 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
     const int wave = tid >> 6;
     const int ib = blockIdx.y;
     const int tile = xcd_tile(blockIdx.x, p.tiles_x * p.tiles_y);
-    const int tx0 = (tile % p.tiles_x) * TILE;
-    const int tr0 = (tile / p.tiles_x) * TILE;
+    int tile_col, tile_row;
+    tile_xy(tile, p.tiles_x, p.tiles_x_magic, tile_col, tile_row);
+    const int tx0 = tile_col * TILE, tr0 = tile_row * TILE;
     const int tx1 = tx0 + TILE - 1, tr1 = tr0 + TILE - 1;
     const int C = CSPEC ? CSPEC : p.C;
 
@@ -787,6 +788,7 @@ hipError_t launch_raster(const RasterParams& p_in, int B, bool visibility_only, 
     if (p.flags & DIRT_FLAG_TILES_SMALL) tile = 16;
     p.tiles_x = (p.W + tile - 1) / tile;
     p.tiles_y = (p.H + tile - 1) / tile;
+    p.tiles_x_magic = tile_magic(p.tiles_x);
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)B);
     {
         const size_t nwg = (size_t)grid.x * grid.y;
