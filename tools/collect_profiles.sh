@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): rocprofv3 kernel-trace stats of bench.py, then separate --pmc passes
 # (never combined with tracing options) for instruction mix, LDS and HBM traffic.  Output: gpurun_out/prof_$1/
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
