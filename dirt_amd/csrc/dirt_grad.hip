@@ -37,6 +37,9 @@
 
 namespace dirt {
 
+#ifndef DIRT_GBK_COALESCED
+#define DIRT_GBK_COALESCED 1
+#endif
 #ifdef DIRT_TRACE
 // Per-wave phase timestamps (s_memtime) for tools/trace_grad.py; compiled only into the tracing build of the library.
 __device__ long long* g_trace_grad = nullptr;
@@ -694,6 +697,34 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         //      dilation phase); at the end of a wave they spread over the ~10 us in which the waves finish.  What they need
         //      -- grad_pixels and "covered" -- is live in the face loop anyway.  K3-2048: gradient kernel 69 -> 66 us. ----
         auto store_background = [&]() {
+#if DIRT_GBK_COALESCED
+        // 4-channel frames: the wave's 32 x 8 pixels in a lane <-> pixel LINEAR mapping (lane l: column l % 32, rows
+        // l / 32 + 2 k), so that every store instruction writes 1 KB of whole lines -- a strip owner's float4 stores are
+        // 16 bytes of every 64.  grad_pixels is read a second time for it (the lines are this workgroup's own, a few
+        // microseconds old: L2 hits) and "covered" comes from the state tile in LDS.
+        if constexpr (NCH == 4 && !STRIDED) {
+            const int cx = lane & 31;
+            float4 gq[4];
+            int fq[4];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ry_ = 2 * k + (lane >> 5), yy = y0 + 8 * wave + ry_;
+                ok[k] = (x0 + cx < W) & (yy < H);
+                const uint32_t off = (uint32_t)((min(yy, H - 1) - row0) * W + min(x0 + cx, W - 1)) * 16u;
+                gq[k] = ld_off<float4>(gpix_t, off);
+                fq[k] = __float_as_int(s_vw[8 * wave + ry_ + 1][cx + 2].y);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ry_ = 2 * k + (lane >> 5), yy = y0 + 8 * wave + ry_;
+                if (!ok[k]) continue;
+                const uint32_t off = (uint32_t)((yy - row0) * W + x0 + cx) * 16u;
+                st_off<float4>(gbk_t, off, fq[k] >= 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : gq[k]);
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!in_px[j]) continue;
