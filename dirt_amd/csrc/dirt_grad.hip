@@ -88,13 +88,13 @@ constexpr int PR = GT + 2;              // staged rows: y0-1 .. y0+32
 constexpr int PS = 36;                  // plane row stride (floats): column (x - x0) + 1 for x0-1 .. x0+34, so that a strip's taps start
                                         // (with the column left of it) at a 16-byte boundary
 constexpr int VS = 36;                  // state tile row stride (float2): column (x - x0) + 2, so that strips are 16-byte aligned
-constexpr int PC = 4;                   // channels per pass: whole channel groups that fit in 4 channels
 constexpr int IS = 34;                  // inbox row stride (float2 cells): cell (ty + 1) * 34 + tx + 2 for ty in -1..8, tx in -1..32
 constexpr int ICELLS = 10 * IS + 4;     // ... of a wave's 32 x 8 region and the one-pixel ring around it (a multiple of 2: 16-byte cells pairs)
 constexpr int RING = 2 * 34 + 2 * 8;    // ring cells: what the wave's pixels sent to pixels of other waves
 
-// grad_kernel<CSPEC, STRIDED>: a workgroup works on CSPEC = 1, 3 or 4 channels (4 = a 3-channel group and a single) of
-// one tile.  Not STRIDED: that is the image's channel count, a compile-time constant (4: with 16-byte aligned pixel
+// grad_kernel<CSPEC, STRIDED>: a workgroup works on CSPEC = 1, 3, 4 or 6 channels (4 = a 3-channel group and a single;
+// 6 = two 3-channel groups, STRIDED only: three workgroups per compute unit, but every 64-byte pixel of a many-channel
+// image is fetched by half as many passes) of one tile.  Not STRIDED: that is the image's channel count, a compile-time constant (4: with 16-byte aligned pixel
 // tensors).  STRIDED: any channel count, cut into PASSES of whole channel groups (dirt/rasterise_ops.py:148-152): the
 // launch covers p.npasses passes of this shape, starting at channel p.c_first, and a workgroup takes one (tile, pass)
 // over `pixels` with a runtime channel stride.  The passes of a tile are consecutive work items of one XCD (xcd_tile),
@@ -106,10 +106,11 @@ constexpr int RING = 2 * 34 + 2 * 8;    // ring cells: what the wave's pixels se
 // where the pairs of rows need ~6.4, but ~1.6 x the float atomics: launched where the memory system has room for them
 // (small frames); otherwise the two rows of a pair (16 x 8 pixels) work on one face.
 template <int CSPEC, bool STRIDED, bool DEBUG, bool ROWS = false>
-__global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
+__global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(GradParams p)
 {
-    static_assert(CSPEC == 1 || CSPEC == 3 || CSPEC == 4, "pass shapes");
+    static_assert(CSPEC == 1 || CSPEC == 3 || CSPEC == 4 || (CSPEC == 6 && STRIDED), "pass shapes");
     constexpr int NPLANES = CSPEC;
+    constexpr int PC = CSPEC == 6 ? 6 : 4;   // channels a staging item holds
     __shared__ __align__(16) float s_pix[NPLANES][PR][PS];  // the pass's channels of `pixels`, edge clamped
     __shared__ __align__(16) float2 s_vw[PR][VS];           // {clip_w, face} of every pixel of the halo'd tile
     __shared__ __align__(16) float2 s_inbox[GTHREADS / 64][ICELLS];  // per wave: (fx, fy) sent to each pixel of its region + ring
@@ -129,15 +130,18 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     // (STRIDED, CSPEC = 4: the launch's passes are 3-channel groups, and only the LAST of them also carries the single that
     // follows the triples -- single_on, wave-uniform.  All passes of an image then go out in one launch and meet in the
     // L2: a pass launched on its own fetches every 64-byte pixel for 4-16 bytes of it, K5: 245 us instead of ~100)
-    int tile, cbase = 0;
+    int tile, cbase = 0, pass_i = 0;
     bool single_on = true;
+    int second_mode = 0;   // CSPEC = 6: the pass's second group is a triple (0), a single (1: the last pass of C % 3 != 0) or absent (2)
     if constexpr (!STRIDED) {
         tile = xcd_tile((int)blockIdx.x, p.tiles_x * p.tiles_y);
     } else {
         const int item = xcd_tile((int)blockIdx.x, p.tiles_x * p.tiles_y * p.npasses);
         tile = item / p.npasses;
-        cbase = p.c_first + (item - tile * p.npasses) * (CSPEC == 1 ? 1 : 3);
-        single_on = CSPEC != 4 || item - tile * p.npasses == p.npasses - 1;
+        pass_i = item - tile * p.npasses;
+        cbase = p.c_first + pass_i * (CSPEC == 1 ? 1 : (CSPEC == 6 ? 6 : 3));
+        single_on = CSPEC != 4 || pass_i == p.npasses - 1;
+        if (CSPEC == 6 && pass_i == p.npasses - 1) second_mode = p.last_second;
     }
     const bool aligned16 = (!STRIDED && CSPEC == 4) ? true : (p.pixels_aligned16 != 0 && (cbase & 3) == 0);
     int tile_col, tile_row;
@@ -198,13 +202,22 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 #pragma unroll
         for (int k = 0; k < PITEMS; ++k) {
             const int cy = min(max(y0 - 1 + st_row + PROWS * k, 0), H - 1);
+#if defined(DIRT_KO_LOADS) || defined(DIRT_KO_PIX)
+            const uint32_t off = 0u * ((uint32_t)(cy - row0) * row_bytes + st_xoff);
+#else
             const uint32_t off = (uint32_t)(cy - row0) * row_bytes + st_xoff;
+#endif
             if (nch == 4 && (C & 3) == 0 && aligned16) {
                 const float4 q = ld_off<float4>(pixels_t, off);
                 v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w;
             } else if (nch == 3) {
                 const Float3 q = ld_off<Float3>(pixels_t, off);
                 v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = 0.f;
+            } else if (CSPEC == 6) {   // two triples / a triple and a single / a triple
+                const Float3 q = ld_off<Float3>(pixels_t, off);
+                v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = 0.f; v[k][PC - 2] = 0.f; v[k][PC - 1] = 0.f;
+                if (nch == 6) { const Float3 r = ld_off<Float3>(pixels_t, off + 12u); v[k][3] = r.x; v[k][PC - 2] = r.y; v[k][PC - 1] = r.z; }
+                else if (nch == 4) v[k][3] = ld_off<float>(pixels_t, off + 12u);
             } else {
 #pragma unroll
                 for (int ch = 0; ch < PC; ++ch) v[k][ch] = ch < nch ? ld_off<float>(pixels_t, off + 4u * ch) : 0.f;
@@ -234,7 +247,8 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     //      Halo positions outside the frame are clamped; they are only ever consulted for interior pixels, whose
     //      neighbours are inside the frame. ----
     float stage_v[PITEMS][PC];
-    stage_load(single_on ? CSPEC : 3, stage_v);
+    const int nch_live = CSPEC == 6 ? (second_mode == 0 ? 6 : (second_mode == 1 ? 4 : 3)) : (single_on ? CSPEC : 3);   // channels the pass reads
+    stage_load(nch_live, stage_v);
     {
         // (the same sweep: column x0 - 1 + tid % 34, rows tid / 34, + 7, ...; threads 238 .. 255 idle)
         constexpr int VITEMS = (PR + PROWS - 1) / PROWS;
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         constexpr int S = (3 + NCHV + 1) & ~1;      // values per vertex (padded to whole pairs)
         constexpr int HP = S / 2;                   // ... as pairs
         constexpr int NV = 3 * S;                   // values per face
-        constexpr int NR = NV <= 16 ? 16 : 24;      // ... padded to what the row reduction takes
+        constexpr int NR = NV <= 16 ? 16 : (NV <= 24 ? 24 : 32);   // ... padded to what the row reduction takes
         static_assert(NV <= NR, "");
         // Order of a vertex's values: the colours first (they arrive as whole registers of the grad_pixels loads), then
         // the position factors with (fx, fy) as one aligned pair: NCHV even: g.., fx, fy, fw, 0;  odd: g.., fw, fx, fy.
@@ -294,7 +308,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         row_value_of_lane<NR>(lane & 15, rv[0], rv[1]);
         const bool odd_row = (blk & 1) != 0;
         if (!ROWS) { rv[0] = odd_row ? rv[1] : rv[0]; rv[1] = -1; }
-        constexpr int NROLES = ROWS && NR == 24 ? 2 : 1;
+        constexpr int NROLES = ROWS && NR >= 24 ? 2 : 1;
         int role_k[NROLES];
         bool role_valid[NROLES];
         float* role_base[NROLES];
@@ -347,7 +361,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                         for (int k = 0; k < 3; ++k)
 #pragma unroll
                             for (int c = 0; c < S; ++c) {
-                                if (!(c < NCHV || c == IX || c == IY || c == IW) || (STRIDED && NCHV == 4 && !single_on && c == 3)) continue;
+                                if (!(c < NCHV || c == IX || c == IY || c == IW) || (STRIDED && NCHV == 4 && !single_on && c == 3) || (NCHV == 6 && c < NCHV && c >= nch_live)) continue;
                                 const float val = bk[j][k] * ((c & 1) ? fp[j][c / 2].y : fp[j][c / 2].x);
                                 float* dstp = c >= NCHV && (c == IX || c == IY || c == IW)
                                     ? reinterpret_cast<float*>(reinterpret_cast<char*>(grad_vertices) + (size_t)((uint32_t)vk[k] * gv_row_bytes)) + (c == IW ? 3 : c - IX)
@@ -426,7 +440,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             if (!ROWS) {   // the two rows of a pair worked on the same face: their totals, added (both rows get the sum)
                 const auto s0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d0), __float_as_uint(d0), false, false);
                 d0 = __uint_as_float(s0[0]) + __uint_as_float(s0[1]);
-                if (NR == 24) {
+                if (NR >= 24) {
                     const auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d1), __float_as_uint(d1), false, false);
                     d1 = __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
                 }
@@ -516,14 +530,19 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
     auto run_pass = [&](auto nch_tag, auto g0_tag) {
         constexpr int NCH = decltype(nch_tag)::value;
         constexpr int G0 = decltype(g0_tag)::value;
-        constexpr int NG = 1 + (NCH - G0);          // channel groups in the pass
+        constexpr bool TWO3 = NCH == 6;             // two 3-channel groups; otherwise a first group of G0 and singles
+        constexpr int NG = TWO3 ? 2 : 1 + (NCH - G0);   // channel groups in the pass
 
         // this strip's grad_pixels
         const uint32_t own_off = own_rel * pixel_bytes;
         float g[4][NCH];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#if defined(DIRT_KO_LOADS) || defined(DIRT_KO_G)
+            const uint32_t off = 0u;
+#else
             const uint32_t off = in_px[j] ? own_off + (uint32_t)j * pixel_bytes : 0u;  // outside the frame: any valid address
+#endif
             bool wide = false;
             if constexpr (NCH == 4) {
                 if (single_on && (C & 3) == 0 && aligned16) {
@@ -541,13 +560,20 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                 g[j][0] = q.x; g[j][1] = q.y; g[j][2] = q.z;
                 wide = true;
             }
+            if constexpr (NCH == 6) {   // (a channel the pass does not have: zero, adds nothing anywhere)
+                const Float3 q = ld_off<Float3>(gpix_t, off);
+                g[j][0] = q.x; g[j][1] = q.y; g[j][2] = q.z; g[j][3] = 0.f; g[j][4] = 0.f; g[j][5] = 0.f;
+                if (second_mode == 0) { const Float3 r = ld_off<Float3>(gpix_t, off + 12u); g[j][3] = r.x; g[j][4] = r.y; g[j][5] = r.z; }
+                else if (second_mode == 1) g[j][3] = ld_off<float>(gpix_t, off + 12u);
+                wide = true;
+            }
             if (!wide) {
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) g[j][ch] = ld_off<float>(gpix_t, off + 4u * ch);
             }
         }
         GMARK();  // 1 loads issued, state tile stored
-        stage_store(single_on ? NCH : 3, stage_v);
+        stage_store(nch_live, stage_v);
         GMARK();  // 2 planes stored
         __syncthreads();
         GMARK();  // 3 barrier passed
@@ -566,10 +592,13 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
             float l1x[4], l1y[4];
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                const int gi = ch < G0 ? 0 : ch - G0 + 1;     // the channel's group
-                const bool single = !(ch < G0 && G0 == 3);     // a 1-channel group: quirk Q1 applies
-                const bool last_of_group = single || ch == G0 - 1;
-                if (STRIDED && NCH == 4 && ch == 3 && !single_on) {   // a pass without the single: nothing of group 1 is used
+                const int gi = TWO3 ? ch / 3 : (ch < G0 ? 0 : ch - G0 + 1);   // the channel's group
+                // ({3,3}: the second group of the launch's last pass may be a single or absent -- second_mode, wave-uniform)
+                const bool single = TWO3 ? (ch >= 3 && second_mode == 1) : !(ch < G0 && G0 == 3);     // a 1-channel group: quirk Q1 applies
+                const bool last_of_group = TWO3 ? (single || ch % 3 == 2) : (single || ch == G0 - 1);
+                const bool first_of_group = TWO3 ? ch % 3 == 0 : ch == 0;     // (of a 3-channel group)
+                if ((STRIDED && NCH == 4 && ch == 3 && !single_on) || (TWO3 && ch >= 3 && (second_mode == 2 || (second_mode == 1 && ch > 3)))) {   // a pass without the single / the second group: nothing of group 1 is used
+                    if (TWO3 && ch > 3 && second_mode == 1) continue;   // (the single was channel 3)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) horiz_m[gi][j] = 0ull;
                     dLx[gi][0] = dLx[gi][1] = dLy[gi][0] = dLy[gi][1] = float2v{0.f, 0.f};
@@ -617,14 +646,14 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                     for (int P = 0; P < 2; ++P) {
                         const float2v gp = float2v{g[2 * P][ch], g[2 * P + 1][ch]};
                         float2v m = gp * Sx[P];
-                        dLx[gi][P] = ch == 0 ? m : dLx[gi][P] + m;
+                        dLx[gi][P] = first_of_group ? m : dLx[gi][P] + m;
                         m = gp * Sy[P];
-                        dLy[gi][P] = ch == 0 ? m : dLy[gi][P] + m;
+                        dLy[gi][P] = first_of_group ? m : dLy[gi][P] + m;
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        l1x[j] = ch == 0 ? fabsf(comp(Sx, j)) : l1x[j] + fabsf(comp(Sx, j));
-                        l1y[j] = ch == 0 ? fabsf(comp(Sy, j)) : l1y[j] + fabsf(comp(Sy, j));
+                        l1x[j] = first_of_group ? fabsf(comp(Sx, j)) : l1x[j] + fabsf(comp(Sx, j));
+                        l1y[j] = first_of_group ? fabsf(comp(Sy, j)) : l1y[j] + fabsf(comp(Sy, j));
                     }
                 } else {
 #pragma unroll
@@ -697,6 +726,42 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         //      dilation phase); at the end of a wave they spread over the ~10 us in which the waves finish.  What they need
         //      -- grad_pixels and "covered" -- is live in the face loop anyway.  K3-2048: gradient kernel 69 -> 66 us. ----
         auto store_background = [&]() {
+        // Many-channel frames with 16-byte aligned pixels: the passes of a launch SHARE the tile -- pass i of n writes rows
+        // i, i + n, ... of it, ALL channels of a pixel at once, in a lane <-> float4 linear mapping, so that every store
+        // instruction writes 1 KB of whole lines (a pass storing its own 12 bytes of every 64-byte pixel writes each line
+        // five times over, partially: K5, ~100 of 550 us).  grad_pixels is read a second time for it (the lines are in
+        // the L2: the passes of the tile have just fetched them); "covered" comes from the state tile in LDS.
+        if constexpr (STRIDED) {
+            if (p.gbk_split >= 0) {   // (uniform over the launch)
+                const int n = p.gbk_split;
+                if (n == 0) return;    // another launch of this call writes grad_background
+                const int per_row = GT * (C >> 2);            // float4 per tile row
+                const float inv_q = 4.f / (float)C;
+                const float* __restrict__ gp_all = p.grad_pixels + origin * C;
+                float* __restrict__ gb_all = p.grad_background + origin * C;
+                for (int r = pass_i + n * wave; r < GT; r += 4 * n) {
+                    const int yy = y0 + r;
+                    if (yy >= H) break;
+                    const uint32_t rowoff = ((uint32_t)(yy - row0) * (uint32_t)W + (uint32_t)x0) * pixel_bytes;
+                    for (int q0 = lane; q0 < per_row; q0 += 256) {
+                        float4 gq[4];
+                        bool ok[4], cov[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int q = q0 + 64 * i;
+                            const int px = (int)(((float)q + 0.5f) * inv_q);
+                            ok[i] = (q < per_row) & (x0 + px < W);
+                            cov[i] = __float_as_int(s_vw[r + 1][min(px, GT - 1) + 2].y) >= 0;
+                            gq[i] = ld_off<float4>(gp_all, ok[i] ? rowoff + 16u * (uint32_t)q : 0u);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (ok[i]) st_off<float4>(gb_all, rowoff + 16u * (uint32_t)(q0 + 64 * i), cov[i] ? make_float4(0.f, 0.f, 0.f, 0.f) : gq[i]);
+                    }
+                }
+                return;
+            }
+        }
 #if DIRT_GBK_COALESCED
         // 4-channel frames: the wave's 32 x 8 pixels in a lane <-> pixel LINEAR mapping (lane l: column l % 32, rows
         // l / 32 + 2 k), so that every store instruction writes 1 KB of whole lines -- a strip owner's float4 stores are
@@ -743,6 +808,12 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
                 st_off<Float3>(gbk_t, off, covered[j] ? Float3{0.f, 0.f, 0.f} : Float3{g[j][0], g[j][1], g[j][2]});
                 wide = true;
             }
+            if constexpr (NCH == 6) {
+                st_off<Float3>(gbk_t, off, covered[j] ? Float3{0.f, 0.f, 0.f} : Float3{g[j][0], g[j][1], g[j][2]});
+                if (second_mode == 0) st_off<Float3>(gbk_t, off + 12u, covered[j] ? Float3{0.f, 0.f, 0.f} : Float3{g[j][3], g[j][4], g[j][5]});
+                else if (second_mode == 1) st_off<float>(gbk_t, off + 12u, covered[j] ? 0.f : g[j][3]);
+                wide = true;
+            }
             if (!wide) {
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) st_off<float>(gbk_t, off + 4u * ch, covered[j] ? 0.f : g[j][ch]);
@@ -785,6 +856,7 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
                 if (STRIDED && NCH == 4 && gi == 1 && !single_on) continue;
+                if (TWO3 && gi == 1 && second_mode == 2) continue;
                 // direction: x if L1(Sx) > L1(Sy) else y (:185), negated on odd (x + y) (:186-190).  The reference's
                 // offsets are in GL buffer orientation (y up): tensor row = y - offset_y.
                 const bool hz = __builtin_amdgcn_inverse_ballot_w64(horiz_m[gi][j]);
@@ -818,8 +890,12 @@ __global__ __launch_bounds__(GTHREADS, 4) void grad_kernel(GradParams p)
         float lb[2][3], lf[2][3];
         gather_positions(fpos_xy, fpos_w, lkey, lb, lf);
         GMARK();  // 6 face loop starts
+#ifndef DIRT_KO_LOOP
         face_loop(integral_constant<int, NCH>{}, g, key, covered, fpos_xy, fpos_w, lkey, lb, lf);
+#endif
+#ifndef DIRT_KO_GBK
         store_background();
+#endif
     };
 
     run_pass(integral_constant<int, CSPEC>{}, integral_constant<int, CSPEC == 1 ? 1 : 3>{});
@@ -883,7 +959,7 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     bool rows = few_tiles && density >= 48;
     if (p.flags & DIRT_FLAG_GRAD_ROWS) rows = true;
     if (p.flags & DIRT_FLAG_GRAD_PAIRS) rows = false;
-    p.c_first = 0; p.npasses = 1;
+    p.c_first = 0; p.npasses = 1; p.gbk_split = -1; p.last_second = 0;
     // the common channel counts: kernels in which the channel count is a compile-time constant
     if (p.C == 4 && p.pixels_aligned16) DIRT_LAUNCH_GRAD(4, false);
     else if (p.C == 3) DIRT_LAUNCH_GRAD(3, false);
@@ -893,15 +969,37 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
         // dirt/rasterise_ops.py:148-152).  Every 3-channel pass goes out in ONE launch -- of the {3,1} body when a single
         // follows the triples: its last pass carries that single, the others switch the single's parts off -- so that the
         // passes of a tile meet in the L2 (a second single, C % 3 == 2, is a launch of its own).
+        // From 6 channels on the triples go out in PAIRS (the {3,3} shape: one staging of the tile, one walk over its faces
+        // and one fetch of every 64-byte pixel for two groups), an odd last triple -- with the single that follows it, if
+        // any -- as the last pass of the same launch, so that all passes of a tile meet in the L2 (a launch of its own for
+        // the last four channels of K5 read both 268 MB tensors a second time); a second single (C % 3 == 2), or the
+        // singles behind an even number of triples, are a launch of the {1} shape.
         const int groups3 = p.C / 3, singles = p.C % 3;
-        if (groups3 >= 1 && singles >= 1) {
-            p.c_first = 0; p.npasses = groups3; DIRT_LAUNCH_GRAD(4, true);
-            if (singles == 2) { p.c_first = 3 * groups3 + 1; p.npasses = 1; DIRT_LAUNCH_GRAD(1, true); }
+        // grad_background: written by the FIRST launch's passes, all channels, whole lines (store_background), where the
+        // pixels are 16-byte aligned; otherwise every pass stores its own channels
+        const bool gbk_shared = (p.C & 3) == 0 && p.pixels_aligned16 != 0;
+        bool gbk_done = false;
+#define DIRT_GBK_PLAN() do { p.gbk_split = !gbk_shared ? -1 : (gbk_done ? 0 : p.npasses); gbk_done = true; } while (0)
+        bool two3 = groups3 >= 2;
+#ifdef DIRT_NO_TWO3
+        two3 = false;
+#endif
+        if (two3) {
+            const bool odd = (groups3 & 1) != 0;
+            p.c_first = 0; p.npasses = (groups3 + 1) / 2; p.last_second = !odd ? 0 : (singles >= 1 ? 1 : 2); DIRT_GBK_PLAN();
+            if (p.debug_thingy) hipLaunchKernelGGL((grad_kernel<6, true, true>), dim3(ntiles * (unsigned)p.npasses, (unsigned)p.B), block, dyn_lds, stream, p);
+            else hipLaunchKernelGGL((grad_kernel<6, true, false>), dim3(ntiles * (unsigned)p.npasses, (unsigned)p.B), block, dyn_lds, stream, p);
+            const int rest = singles - (odd && singles >= 1 ? 1 : 0);   // singles not yet done
+            if (rest >= 1) { p.c_first = p.C - rest; p.npasses = rest; DIRT_GBK_PLAN(); DIRT_LAUNCH_GRAD(1, true); }
+        } else if (groups3 >= 1 && singles >= 1) {
+            p.c_first = 0; p.npasses = groups3; DIRT_GBK_PLAN(); DIRT_LAUNCH_GRAD(4, true);
+            if (singles == 2) { p.c_first = 3 * groups3 + 1; p.npasses = 1; DIRT_GBK_PLAN(); DIRT_LAUNCH_GRAD(1, true); }
         } else if (groups3 >= 1) {
-            p.c_first = 0; p.npasses = groups3; DIRT_LAUNCH_GRAD(3, true);
+            p.c_first = 0; p.npasses = groups3; DIRT_GBK_PLAN(); DIRT_LAUNCH_GRAD(3, true);
         } else {
-            p.c_first = 0; p.npasses = singles; DIRT_LAUNCH_GRAD(1, true);
+            p.c_first = 0; p.npasses = singles; DIRT_GBK_PLAN(); DIRT_LAUNCH_GRAD(1, true);
         }
+#undef DIRT_GBK_PLAN
     }
 #undef DIRT_LAUNCH_GRAD
     return hipGetLastError();

@@ -83,6 +83,9 @@ struct GradParams {
     uint32_t tiles_x_magic;    // tile_magic(tiles_x), filled by launch_grad
     int pixels_aligned16;      // the [B,H,W,C] tensors may be accessed with 16-byte loads / stores, filled by launch_grad
     int c_first, npasses;      // the launch's channel passes (see grad_kernel<CSPEC, STRIDED>), filled by launch_grad
+    int last_second;           // the {3,3} shape: what the LAST pass of the launch has as its second group: 0 a triple, 1 a single, 2 nothing
+    int gbk_split;             // strided launches: > 0: the launch's passes write grad_background of ALL channels, a share of the tile's
+                               // rows each (whole lines); 0: another launch of the call does; < 0: every pass stores its own channels
     float two_over_w, two_over_h;  // 2 / W, 2 / H (pixel -> NDC), filled by launch_grad
 };
 

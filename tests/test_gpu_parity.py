@@ -335,7 +335,7 @@ def test_many_dilated_pairs_per_wave(gpu, oracle, C):
 
 
 @pytest.mark.parametrize('W', [32, 33, 34, 35, 61, 64, 65, 67])
-@pytest.mark.parametrize('C', [1, 4, 5])
+@pytest.mark.parametrize('C', [1, 4, 5, 7, 10, 16])
 def test_right_border_alias_taps(gpu, oracle, W, C):
     """Quirk Q1 at the right image border: the aliased "channels" 1, 2 of a 1-channel group are the next two elements
     of the flattened slice, which for the last interior columns lie in the NEXT image row (and past the end of the
@@ -352,6 +352,26 @@ def test_right_border_alias_taps(gpu, oracle, W, C):
     _assert_grad_close(gvc.cpu().numpy(), ow, 'grad_vertex_colors', 'grad_vertex_colors')
     _assert_grad_close(gv.cpu().numpy(), ow, 'grad_vertices', 'grad_vertices')
 
+
+@pytest.mark.parametrize('C', [2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20])
+def test_channel_group_passes(gpu, oracle, C):
+    """Channel counts other than 1, 3, 4 are cut into passes of whole channel groups (dirt/rasterise_ops.py:148-152: triples
+    while >= 3 channels remain, then singles): pairs of triples ({3,3}), whose last pass may carry a triple and the first
+    single ({3,1}) or a lone triple, then the remaining singles -- every combination of C // 3 odd / even and C % 3, on a
+    frame that is no multiple of the tile, with and without the debug output (one instantiation each), a batch of two.
+    grad_background -- written by the first launch's passes in shares where C % 4 == 0, by every pass otherwise -- exact."""
+    H, W = 70, 91
+    s = scenes.batch_scene(90, H, W, C, seeds=[31 + C, 32 + C], r_lo=0.03, r_hi=0.3)
+    want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
+    for flags in (0, 1):
+        ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'], flags=flags, want_debug=True)
+        for dbg_on in (False, True):
+            gb, gv, gvc, dbg = ops._op_rasterise_grad(_t(s['vertices'], gpu), _t(s['faces'], gpu), _t(want, gpu),
+                                                      _t(s['grad_pixels'], gpu), H, W, C, flags=flags, want_debug=dbg_on)
+            assert np.array_equal(gb.cpu().numpy().view(np.uint32), ow['grad_background'].view(np.uint32)), 'C=%d grad_background' % C
+            if dbg_on:
+                assert np.array_equal(dbg.cpu().numpy(), ow['debug_thingy']), 'C=%d debug_thingy' % C
+            parity.grads_close(gv, gvc, ow, 'C=%d flags=%d' % (C, flags), tol=5e-6)
 
 def test_duplicate_index_triples(gpu, oracle):
     """Distinct faces over the SAME three vertex indices count as one face for the dilation test
@@ -413,7 +433,7 @@ def test_misaligned_views_are_accepted(gpu, oracle):
     _assert_grad_close(vc.grad.cpu().numpy(), ow, 'grad_vertex_colors', 'gvc')
 
 
-@pytest.mark.parametrize('C', [1, 3, 4, 5])
+@pytest.mark.parametrize('C', [1, 3, 4, 5, 9, 10, 16])
 @pytest.mark.parametrize('shape', [pytest.param(0x2000, id='pairs'), pytest.param(0x1000, id='rows'), pytest.param(0x4000, id='px1')])
 def test_non_finite_grad_pixels_stay_with_their_own_face(gpu, oracle, C, shape):
     """The reference adds a pixel's terms to the vertices of that pixel's face only (csrc/rasterise_grad_egl.cu:140,228-230):
@@ -438,8 +458,8 @@ def test_non_finite_grad_pixels_stay_with_their_own_face(gpu, oracle, C, shape):
     assert np.isfinite(ow['grad_vertices']).mean() > 0.5            # ... and most of the mesh stays finite
     d = {k: _t(b[k], gpu) for k in b}
     px, state = ops._op_rasterise(d['background'], d['vertices'], d['vertex_colors'], d['faces'], H, W, C, keep_state=True)
-    if C == 5 and shape == 0x4000:
-        pytest.skip('the one-pixel-per-lane kernel takes 1, 3 or 4 channels')
+    if C >= 5 and shape != 0x2000:
+        pytest.skip('many-channel frames have one kernel shape (passes of channel groups)')
     for st in (state, None):
         gb, gv, gvc, _ = ops._op_rasterise_grad(d['vertices'], d['faces'], px, d['grad_pixels'], H, W, C, flags=shape, state=st)
         assert np.array_equal(gb.cpu().numpy().view(np.uint32), ow['grad_background'].view(np.uint32)), 'grad_background'

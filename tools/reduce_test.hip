@@ -31,7 +31,7 @@ bool run()
     float o[256];
     hipMemcpy(o, dout, 1024, hipMemcpyDeviceToHost);
     bool ok = true;
-    bool seen[4][24] = {};
+    bool seen[4][32] = {};
     for (int l = 0; l < 64; ++l) {
         const int row = l >> 4;
         for (int s = 0; s < 2; ++s) {
@@ -52,7 +52,7 @@ bool run()
 
 int main()
 {
-    const bool ok = run<24>() & run<16>();
+    const bool ok = run<24>() & run<16>() & run<32>();
     printf("reduce_test: %s\n", ok ? "PASS" : "FAIL");
     return ok ? 0 : 1;
 }
