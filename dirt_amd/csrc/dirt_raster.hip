@@ -311,6 +311,41 @@ __device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec
     }
 }
 
+// Two candidates against the wave's one block (NB = 1: 16 x 16 tiles, one pixel per lane), the arithmetic of
+// raster_candidate operation for operation, the two chains interleaved.  Small frames run ONE wave per SIMD: nothing hides
+// a dependent instruction's latency but the wave's own independent work, and a single candidate is one chain of ~40
+// instructions (437 clocks per candidate at K3-256); two candidates at a time share the branches and fill each other's
+// gaps.  Update order is the list order (t0 before t1), as in the one-candidate loop.
+__device__ __forceinline__ void raster_candidate_pair(const TileRec& t0, const TileRec& t1, const FaceRec* __restrict__ recs, int ci0, int ci1,
+                                                      float dx, float dy, double px, double py, unsigned long long& best, int& cbest)
+{
+    const float E00 = fmaf(t0.a[0], dx, fmaf(t0.b[0], dy, t0.c[0])), E10 = fmaf(t1.a[0], dx, fmaf(t1.b[0], dy, t1.c[0]));
+    const float E01 = fmaf(t0.a[1], dx, fmaf(t0.b[1], dy, t0.c[1])), E11 = fmaf(t1.a[1], dx, fmaf(t1.b[1], dy, t1.c[1]));
+    const float E02 = fmaf(t0.a[2], dx, fmaf(t0.b[2], dy, t0.c[2])), E12 = fmaf(t1.a[2], dx, fmaf(t1.b[2], dy, t1.c[2]));
+    const float m0 = fminf(fminf(E00, E01), E02), m1 = fminf(fminf(E10, E11), E12);
+    unsigned long long cov0 = __builtin_amdgcn_ballot_w64(m0 > t0.bound), cov1 = __builtin_amdgcn_ballot_w64(m1 > t1.bound);
+    const unsigned long long uns0 = __builtin_amdgcn_ballot_w64(!(m0 < -t0.bound)) & ~cov0, uns1 = __builtin_amdgcn_ballot_w64(!(m1 < -t1.bound)) & ~cov1;
+    if (__builtin_expect((uns0 | uns1) != 0ull, 0)) {
+        bool c0 = false, c1 = false;
+        if (__builtin_amdgcn_inverse_ballot_w64(uns0)) c0 = covered_exact(recs + t0.face, px, py);
+        if (__builtin_amdgcn_inverse_ballot_w64(uns1)) c1 = covered_exact(recs + t1.face, px, py);
+        cov0 |= __builtin_amdgcn_ballot_w64(c0); cov1 |= __builtin_amdgcn_ballot_w64(c1);
+    }
+    if ((cov0 | cov1) == 0ull) return;
+    const double q0 = fma(t0.zp[0], px, fma(t0.zp[1], py, t0.zp[2])), q1 = fma(t1.zp[0], px, fma(t1.zp[1], py, t1.zp[2]));
+    const uint32_t z0 = (uint32_t)__double_as_longlong(q0 + 4503599627370496.0), z1 = (uint32_t)__double_as_longlong(q1 + 4503599627370496.0);
+    const unsigned long long in0 = __builtin_amdgcn_ballot_w64((unsigned long long)__double_as_longlong(q0) <= 0x416FFFFFE0000000ull);
+    const unsigned long long in1 = __builtin_amdgcn_ballot_w64((unsigned long long)__double_as_longlong(q1) <= 0x416FFFFFE0000000ull);
+    const unsigned long long key0 = ((unsigned long long)z0 << 32) | (unsigned long long)(uint32_t)t0.face;
+    const unsigned long long key1 = ((unsigned long long)z1 << 32) | (unsigned long long)(uint32_t)t1.face;
+    const bool w0 = __builtin_amdgcn_inverse_ballot_w64(cov0 & in0 & __builtin_amdgcn_ballot_w64(key0 < best));
+    const unsigned long long b1 = w0 ? key0 : best;
+    const int c1i = w0 ? ci0 : cbest;
+    const bool w1 = __builtin_amdgcn_inverse_ballot_w64(cov1 & in1 & __builtin_amdgcn_ballot_w64(key1 < b1));
+    best = w1 ? key1 : b1;
+    cbest = w1 ? ci1 : c1i;
+}
+
 // The backward pass's state of one pixel -- csrc/shaders.cpp:64-77: {clip_w, face} and two of the three barycentrics
 // (encode_bary, dirt_device.h; the face index stands for the index triple) -- or the clear values of
 // csrc/rasterise_grad_egl.cpp:442-445.
@@ -557,6 +592,19 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
                 // (no software prefetch of the next candidate's record: holding two records costs 20 registers in a kernel
                 // that sits at the limit for four workgroups per CU, and the other waves of the SIMD cover the LDS latency:
                 // K3 raster 24.3 -> 21.7 us without it)
+#ifndef DIRT_RASTER_NO_PAIRS
+                if constexpr (NB == 1) {   // small frames: two candidates per trip (raster_candidate_pair)
+                    while (m & (m - 1)) {
+                        const int k0 = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const int k1 = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const TileRec t0 = s_rec[k0], t1 = s_rec[k1];
+                        raster_candidate_pair(t0, t1, recs, round == 0 ? cb + k0 : SHADE_CAP, round == 0 ? cb + k1 : SHADE_CAP, dxl[0], dyl[0], px[0], py[0], best[0], cbest[0]);
+                        TRACE_CNT();
+                    }
+                }
+#endif
                 while (m) {
                     const int k = __ffsll((long long)m) - 1;
                     m &= m - 1;
