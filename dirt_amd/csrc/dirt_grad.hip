@@ -846,10 +846,10 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
             const int fl = j == 0 ? f_l : f_own[j - 1], fr = j == 3 ? f_r : f_own[j + 1];
             // (the pixel's own face as the state tile has it: an uncovered pixel, -1, differs from any face)
             const float wo = interior[j] ? w_own[j] : -INFINITY;   // pixels on the frame's border are never dilated (:155)
-            const float qL = (fl != f_own[j]) & (wo > wl) ? wl : 0.f;
-            const float qR = (fr != f_own[j]) & (wo > wr) ? wr : 0.f;
-            const float qU = (f_up[j] != f_own[j]) & (wo > w_up[j]) ? w_up[j] : 0.f;
-            const float qD = (f_dn[j] != f_own[j]) & (wo > w_dn[j]) ? w_dn[j] : 0.f;
+            const float qL = ((fl != f_own[j]) & (wo > wl)) ? wl : 0.f;
+            const float qR = ((fr != f_own[j]) & (wo > wr)) ? wr : 0.f;
+            const float qU = ((f_up[j] != f_own[j]) & (wo > w_up[j])) ? w_up[j] : 0.f;
+            const float qD = ((f_dn[j] != f_own[j]) & (wo > w_dn[j])) ? w_dn[j] : 0.f;
             const bool pos = (j & 1) ? !pos0 : pos0;   // first attempt towards +x / up (:191), else -x / down
             const float qx1 = pos ? qR : qL, qx2 = pos ? qL : qR, qy1 = pos ? qU : qD, qy2 = pos ? qD : qU;
             const float rcp_own = __builtin_amdgcn_rcpf(w_own[j]);
