@@ -144,6 +144,13 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
         if (CSPEC == 6 && pass_i == p.npasses - 1) second_mode = p.last_second;
     }
     const bool aligned16 = (!STRIDED && CSPEC == 4) ? true : (p.pixels_aligned16 != 0 && (cbase & 3) == 0);
+    // ({3,3} passes of frames whose pixels are 16-byte aligned, C % 4 == 0: a pass starts at channel 6 i, i.e. at byte 0 or 8
+    // of a 16-byte unit, and a last pass with a single (C % 3 == 1) at a multiple of 4 channels -- a lone last triple does not occur)
+#ifdef DIRT_NO_WIDE6
+    const bool wide6 = false;
+#else
+    const bool wide6 = CSPEC == 6 && p.pixels_aligned16 != 0 && (C & 3) == 0;
+#endif
     int tile_col, tile_row;
     tile_xy(tile, p.tiles_x, p.tiles_x_magic, tile_col, tile_row);
     const int x0 = tile_col * GT, y0 = tile_row * GT;
@@ -213,6 +220,16 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
             } else if (nch == 3) {
                 const Float3 q = ld_off<Float3>(pixels_t, off);
                 v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = 0.f;
+            } else if (CSPEC == 6 && wide6) {   // 16-byte aligned pixels: the pass's 24 (16) bytes as 16 + 8 (8 + 16) byte accesses
+                if ((cbase & 3) == 0) {
+                    const float4 q = ld_off<float4>(pixels_t, off);
+                    v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = q.w; v[k][PC - 2] = 0.f; v[k][PC - 1] = 0.f;
+                    if (nch == 6) { const float2 r = ld_off<float2>(pixels_t, off + 16u); v[k][PC - 2] = r.x; v[k][PC - 1] = r.y; }
+                } else {
+                    const float2 q = ld_off<float2>(pixels_t, off);
+                    const float4 r = ld_off<float4>(pixels_t, off + 8u);
+                    v[k][0] = q.x; v[k][1] = q.y; v[k][2] = r.x; v[k][3] = r.y; v[k][PC - 2] = r.z; v[k][PC - 1] = r.w;
+                }
             } else if (CSPEC == 6) {   // two triples / a triple and a single / a triple
                 const Float3 q = ld_off<Float3>(pixels_t, off);
                 v[k][0] = q.x; v[k][1] = q.y; v[k][2] = q.z; v[k][3] = 0.f; v[k][PC - 2] = 0.f; v[k][PC - 1] = 0.f;
@@ -561,11 +578,24 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
                 wide = true;
             }
             if constexpr (NCH == 6) {   // (a channel the pass does not have: zero, adds nothing anywhere)
+              if (wide6) {
+                if ((cbase & 3) == 0) {
+                    const float4 q = ld_off<float4>(gpix_t, off);
+                    g[j][0] = q.x; g[j][1] = q.y; g[j][2] = q.z; g[j][3] = q.w; g[j][4] = 0.f; g[j][5] = 0.f;
+                    if (second_mode == 0) { const float2 r = ld_off<float2>(gpix_t, off + 16u); g[j][4] = r.x; g[j][5] = r.y; }
+                } else {
+                    const float2 q = ld_off<float2>(gpix_t, off);
+                    const float4 r = ld_off<float4>(gpix_t, off + 8u);
+                    g[j][0] = q.x; g[j][1] = q.y; g[j][2] = r.x; g[j][3] = r.y; g[j][4] = r.z; g[j][5] = r.w;
+                }
+                wide = true;
+              } else {
                 const Float3 q = ld_off<Float3>(gpix_t, off);
                 g[j][0] = q.x; g[j][1] = q.y; g[j][2] = q.z; g[j][3] = 0.f; g[j][4] = 0.f; g[j][5] = 0.f;
                 if (second_mode == 0) { const Float3 r = ld_off<Float3>(gpix_t, off + 12u); g[j][3] = r.x; g[j][4] = r.y; g[j][5] = r.z; }
                 else if (second_mode == 1) g[j][3] = ld_off<float>(gpix_t, off + 12u);
                 wide = true;
+              }
             }
             if (!wide) {
 #pragma unroll
