@@ -27,6 +27,7 @@ def main():
         return g[..., :3] * g[..., 3:4]
 
     def step_shared():
+        bg.grad = v.grad = a.grad = None   # (as an optimiser's zero_grad(set_to_none=True): no 268 MB accumulate-into-.grad kernel)
         px = ops.rasterise_deferred(bg, v, a, f, shader)
         px.backward(d)
 
@@ -39,8 +40,20 @@ def main():
         dg, = torch.autograd.grad(px, [gi], d[None])
         ops._op_rasterise_grad(v[None], f[None], g, dg.contiguous(), H, W, C)
 
-    out = {'config': config, 'steps': steps}
-    for name, fn in (('shared_state', step_shared), ('rerender', step_rerender)):
+    def step_shared_raw():  # the raw ops of step_rerender with the forward's state shared: no autograd engine in either leg
+        with torch.no_grad():
+            g, state = ops._op_rasterise(bg[None], v[None], a[None], f[None], H, W, C, keep_state=True, state_channels=4)
+        gi = g.detach().requires_grad_(True)
+        px = shader(gi)
+        ops._op_rasterise_grad(v[None], f[None], px.detach().contiguous(), d[None], H, W, 3, state=state, state_outputs=False)
+        dg, = torch.autograd.grad(px, [gi], d[None])
+        ops._op_rasterise_grad(v[None], f[None], g, dg.contiguous(), H, W, C, state=state, state_outputs=False)
+
+    out = {'config': config, 'steps': steps,
+           'legs': 'shared_state: dirt_amd.rasterise_deferred(...).backward() (autograd engine: ~0.1 ms of host time per step); '
+                   'shared_state_raw / rerender: the same arithmetic as raw op calls, with the forward state shared / with a fresh '
+                   'set-up + visibility render in each gradient call'}
+    for name, fn in (('shared_state', step_shared), ('shared_state_raw', step_shared_raw), ('rerender', step_rerender)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
