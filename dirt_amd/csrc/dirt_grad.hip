@@ -37,6 +37,11 @@
 
 namespace dirt {
 
+// Preprocessor switches: none is defined for the product library (dirt_amd/build.py).  They exist so that the A/B and
+// knock-out figures of profiles/EXPERIMENTS.md can be reproduced (tools/variants.sh builds a library per flag set,
+// tools/ab.sh times it):  DIRT_TRACE (per-wave phase timestamps, tools/trace_grad.py);  DIRT_GRAD_NO_ATOMICS,
+// DIRT_KO_LOADS / _PIX / _G / _GBK / _LOOP (knock-outs: wrong results by design);  DIRT_GBK_COALESCED=0, DIRT_NO_WIDE6,
+// DIRT_NO_TWO3 (the previous form of a change that was kept: same results, slower).
 #ifndef DIRT_GBK_COALESCED
 #define DIRT_GBK_COALESCED 1
 #endif
