@@ -8,6 +8,7 @@ the same values bit for bit."""
 import torch
 
 from . import _lib
+from . import rasterise_ops as _ops
 
 
 def uvs_to_pixel_indices(uvs, texture_shape, mode='repeat'):
@@ -73,9 +74,9 @@ class _SampleTextureUV(torch.autograd.Function):
         n = uvs.numel() // 2
         ht, wt, ct = (int(d) for d in texture.shape)
         out = torch.empty(tuple(uvs.shape[:-1]) + (ct,), dtype=torch.float32, device=texture.device)
-        with torch.cuda.device(texture.device):
+        with _ops._on_device(texture.device):
             rc = lib.dirt_texture_sample_forward(texture.data_ptr(), src.data_ptr(), out.data_ptr(), n, ht, wt, ct, stride, flags,
-                                                 torch.cuda.current_stream(texture.device).cuda_stream)
+                                                 _ops._stream_handle(texture.device))
         if rc:
             raise ValueError(lib.dirt_texture_last_error().decode())
         ctx.save_for_backward(texture, src)
@@ -95,10 +96,10 @@ class _SampleTextureUV(torch.autograd.Function):
         grad_out = grad_out.contiguous().to(torch.float32)
         grad_texture = torch.empty_like(texture)
         grad_uvs = torch.empty(uv_shape, dtype=torch.float32, device=texture.device) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(texture.device):
+        with _ops._on_device(texture.device):
             rc = lib.dirt_texture_sample_backward(texture.data_ptr(), src.data_ptr(), grad_out.data_ptr(), grad_texture.data_ptr(),
                                                   grad_uvs.data_ptr() if grad_uvs is not None else None, n, ht, wt, ct, stride, 2, flags,
-                                                  torch.cuda.current_stream(texture.device).cuda_stream)
+                                                  _ops._stream_handle(texture.device))
         if rc:
             raise ValueError(lib.dirt_texture_last_error().decode())
         return grad_texture, grad_uvs, None

@@ -373,6 +373,23 @@ def test_channel_group_passes(gpu, oracle, C):
                 assert np.array_equal(dbg.cpu().numpy(), ow['debug_thingy']), 'C=%d debug_thingy' % C
             parity.grads_close(gv, gvc, ow, 'C=%d flags=%d' % (C, flags), tol=5e-6)
 
+def test_stream_handle_fallback_and_device_guard(gpu, oracle, monkeypatch):
+    """The wrappers take the current stream's handle from torch's C binding where it exists and guard the device only
+    when it is not current (host-side cost); the public-API fallbacks of both must give the same result."""
+    s = _batched(scenes.rand_scene(50, 40, 56, 3, 12, 0.05, 0.3))
+    want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
+    args = (_t(s['background'], gpu), _t(s['vertices'], gpu), _t(s['vertex_colors'], gpu), _t(s['faces'], gpu), 40, 56, 3)
+    assert ops._stream_handle(gpu) == torch.cuda.current_stream(gpu).cuda_stream
+    side = torch.cuda.Stream(device=gpu)
+    with torch.cuda.stream(side):
+        assert ops._stream_handle(gpu) == side.cuda_stream
+    monkeypatch.setattr(ops, '_get_raw_stream', None)
+    monkeypatch.setattr(ops, '_on_device', lambda dev: torch.cuda.device(dev))
+    assert ops._stream_handle(gpu) == torch.cuda.current_stream(gpu).cuda_stream
+    got = ops._op_rasterise(*args).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_duplicate_index_triples(gpu, oracle):
     """Distinct faces over the SAME three vertex indices count as one face for the dilation test
     (csrc/rasterise_grad_egl.cu:86-89 compares the index triples, not the primitives)."""
