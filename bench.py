@@ -240,6 +240,11 @@ def main():
         ops.rasterise_batch(bg_l, v_l, vc_l, f, H, W, C).backward(g)
 
     ms_per_step_autograd = sorted(event_region(autograd_step, max(20, min(args.steps, 200))) for _ in range(3))[1]
+    # ... and with torch's backward engine kept on the calling thread (torch.autograd.set_multithreading_enabled(False): a
+    # user-side switch): the engine otherwise hands every CUDA node to a per-device worker thread and waits for it -- two
+    # thread wake-ups per backward(), which is most of what the autograd path costs over the raw ops at this step length
+    with torch.autograd.set_multithreading_enabled(False):
+        ms_per_step_autograd_1t = sorted(event_region(autograd_step, max(20, min(args.steps, 200))) for _ in range(3))[1]
     del bg_l, v_l, vc_l
 
     # ---- the other frame sizes BASELINE.json's north_star asks for (256^2 and 2048^2, same mesh): short legs, one scene ----
@@ -462,8 +467,10 @@ def main():
             'timing': 'ms_per_step / value: wall clock over the K steps between barrier + synchronize (the contract); '
                       'ms_per_step_events_median: the same K steps between a HIP-event pair on the launch stream, no synchronisation '
                       'after the warm-up, median of 5 regions (SURVEY.md 8d); ms_per_step_autograd: dirt.rasterise_batch(...).backward() '
-                      'with leaf tensors and dense gradients, event-timed',
+                      'with leaf tensors and dense gradients, event-timed; ..._engine_on_calling_thread: the same under '
+                      'torch.autograd.set_multithreading_enabled(False) (no hand-off to the per-device backward thread)',
             'ms_per_step_autograd': ms_per_step_autograd,
+            'ms_per_step_autograd_engine_on_calling_thread': ms_per_step_autograd_1t,
             'other_configs': other_configs,
             'ms_per_step_eager': calib['eager_ms_per_step'], 'ms_per_step_graph': calib['graph_ms_per_step'],
             'launch_calibration': calib,
