@@ -15,6 +15,7 @@ ABI_VERSION = 2
 FLAG_Q1_INTENDED = 1
 FLAG_KEEP_STATE = 2
 FLAG_REUSE_STATE = 4
+FLAG_DENSE_FROM_STATE = 8   # backward: sum in the state's interleaved accumulators, copy out into the caller's dense tensors
 FLAG_PROFILE = 0x100
 FLAG_TILES_LARGE = 0x200
 FLAG_TILES_SMALL = 0x400

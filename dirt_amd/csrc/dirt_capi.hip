@@ -323,7 +323,10 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
     // are cleared by one launch; grad_background and debug_thingy are fully written by the gradient
     // kernel instead
     // the caller's outputs are dense unless they are the state's own accumulators (dirt_state_grad_buffers)
-    const bool state_outputs = (flags & DIRT_FLAG_REUSE_STATE) && grad_vertices == c.gv && grad_vertex_colors == c.gvc;
+    // (... or, DIRT_FLAG_DENSE_FROM_STATE, dense tensors that receive a copy of those accumulators after the kernel)
+    const bool own_outputs = (flags & DIRT_FLAG_REUSE_STATE) && grad_vertices == c.gv && grad_vertex_colors == c.gvc;
+    const bool unpack = (flags & DIRT_FLAG_REUSE_STATE) && (flags & DIRT_FLAG_DENSE_FROM_STATE) && !own_outputs;
+    const bool state_outputs = own_outputs || unpack;
     if (flags & DIRT_FLAG_REUSE_STATE) {
         // records + visibility were left in this workspace by the forward pass; so were cleared gradient
         // accumulators: if the caller's outputs ARE those nothing is left to do
@@ -350,14 +353,15 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
     dirt::GradParams gp;
     gp.state_a = c.state_a; gp.state_b = c.state_b; gp.faces = faces; gp.shared_faces = (flags & DIRT_FLAG_SHARED_FACES) ? 1 : 0;
     gp.pixels = pixels; gp.grad_pixels = grad_pixels;
-    gp.grad_background = grad_background; gp.grad_vertices = grad_vertices;
-    gp.grad_vertex_colors = grad_vertex_colors; gp.debug_thingy = debug_thingy;
+    gp.grad_background = grad_background; gp.grad_vertices = unpack ? c.gv : grad_vertices;
+    gp.grad_vertex_colors = unpack ? c.gvc : grad_vertex_colors; gp.debug_thingy = debug_thingy;
     gp.gv_stride = state_outputs ? w.acc_stride : 4;
     gp.gvc_stride = state_outputs ? w.acc_stride : C;
     gp.B = B; gp.V = V; gp.F = F; gp.H = H; gp.W = W; gp.C = C; gp.flags = flags;
     {
         Scope sc(prof, SLOT_GRAD, stream);
         HIP_TRY(who, dirt::launch_grad(gp, stream));
+        if (unpack) HIP_TRY(who, dirt::launch_unpack(c.gv, c.gvc, w.acc_stride, grad_vertices, grad_vertex_colors, C, (size_t)B * V, stream));
     }
     g_last_error[0] = 0;
     return DIRT_OK;

@@ -92,6 +92,7 @@ struct GradParams {
 BinGrid make_bin_grid(int H, int W);
 void chunking(int F, int& nchunk, int& chunk_faces);
 hipError_t launch_zero(void* b, size_t b_bytes, void* c, size_t c_bytes, hipStream_t stream);
+hipError_t launch_unpack(const float* acc_gv, const float* acc_gvc, int acc_stride, float* gv, float* gvc, int C, size_t rows, hipStream_t stream);
 hipError_t launch_geometry(const GeomParams& g, hipStream_t stream);
 hipError_t launch_raster(const RasterParams& p, int B, bool visibility_only, hipStream_t stream);
 hipError_t launch_grad(const GradParams& p, hipStream_t stream);

@@ -797,6 +797,26 @@ hipError_t launch_zero(void* b, size_t b_bytes, void* c, size_t c_bytes, hipStre
     return hipGetLastError();
 }
 
+// The state's interleaved gradient accumulators (one row {x, y, z, w, c_0 ..} of acc_stride floats per vertex) copied out
+// into dense [rows, 4] / [rows, C] tensors: one thread per vertex (DIRT_FLAG_DENSE_FROM_STATE).
+__global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ acc_gv, const float* __restrict__ acc_gvc, int acc_stride,
+                                                     float* __restrict__ gv, float* __restrict__ gvc, int C, size_t rows)
+{
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    *reinterpret_cast<float4*>(gv + 4 * r) = *reinterpret_cast<const float4*>(acc_gv + r * (size_t)acc_stride);
+    const float* __restrict__ a = acc_gvc + r * (size_t)acc_stride;
+    float* __restrict__ o = gvc + r * (size_t)C;
+    for (int c = 0; c < C; ++c) o[c] = a[c];
+}
+
+hipError_t launch_unpack(const float* acc_gv, const float* acc_gvc, int acc_stride, float* gv, float* gvc, int C, size_t rows, hipStream_t stream)
+{
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, acc_gv, acc_gvc, acc_stride, gv, gvc, C, rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_geometry(const GeomParams& g, hipStream_t stream)
 {
     if (g.B == 0) return hipSuccess;

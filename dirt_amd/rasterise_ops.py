@@ -212,8 +212,10 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
     `state`: the workspace a keep_state forward of the same vertices / faces / frame left behind; the call then
     neither sets up nor renders again.  With state_outputs=True (one backward per forward: autograd) the vertex
     gradients accumulate in the buffers that forward pre-cleared inside the state and the returned tensors are
-    views of it; with state_outputs=False they are fresh tensors, so a state can serve any number of backward
-    calls (deferred shading: one for the shaded image, one for the G-buffer)."""
+    views of it; with state_outputs='dense' they accumulate there too and the library copies them out into fresh DENSE
+    tensors with one more launch (DIRT_FLAG_DENSE_FROM_STATE: what the autograd path hands back); with
+    state_outputs=False they are fresh tensors, cleared and added into directly, so a state can serve any number of
+    backward calls (deferred shading: one for the shaded image, one for the G-buffer)."""
     lib = _lib.load()
     _check_backward_shapes(vertices, faces, pixels, grad_pixels)
     if tuple(pixels.shape[1:]) != (height, width, channels):
@@ -231,9 +233,9 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
             state = None  # sized for fewer channels than this call has: render again
         if state is not None and getattr(state, '_dirt_channels', channels) != channels:
             state_outputs = False  # the accumulators inside the state were laid out (and cleared) for another channel count
-        if state is not None and not state_outputs:
+        if state is not None and (not state_outputs or state_outputs == 'dense'):
             ws = state
-            flags |= _lib.FLAG_REUSE_STATE
+            flags |= _lib.FLAG_REUSE_STATE | (_lib.FLAG_DENSE_FROM_STATE if state_outputs == 'dense' else 0)
             grad_vertices = torch.empty_like(vertices)
             grad_vertex_colors = torch.empty((B, V, channels), dtype=torch.float32, device=dev)
         elif state is not None:
@@ -313,15 +315,15 @@ class _Rasterise(torch.autograd.Function):
         # the reference's grad op is pure (csrc/rasterise_grad_egl.cu:244-250 clears its outputs on every call).
         first = not getattr(ctx, 'state_outputs_used', False)
         ctx.state_outputs_used = True
+        # the state's accumulators are interleaved (one row {x, y, z, w, colours} per vertex); autograd gets DENSE tensors,
+        # as the reference's op returns -- strided views would pin the whole state (records + 16 bytes per pixel) for as
+        # long as a gradient lives, make `.view(-1)` raise, and be cloned by AccumulateGrad anyway: the library copies them
+        # out itself (one launch inside the same call instead of two torch copies)
+        if grad_pixels.dtype != torch.float32:
+            grad_pixels = grad_pixels.to(torch.float32)
         grad_background, grad_vertices, grad_vertex_colors, _ = _op_rasterise_grad(
-            vertices, faces, pixels, grad_pixels.to(torch.float32), height, width, channels, state=ctx.state,
-            state_outputs=first)
-        if first:
-            # the state's accumulators are interleaved (one row {x, y, z, w, colours} per vertex): hand autograd DENSE
-            # tensors, as the reference's op returns -- strided views would pin the whole state (records + 16 bytes per
-            # pixel) for as long as a gradient lives, make `.view(-1)` raise, and be cloned by AccumulateGrad anyway
-            grad_vertices = grad_vertices.contiguous()
-            grad_vertex_colors = grad_vertex_colors.contiguous()
+            vertices, faces, pixels, grad_pixels, height, width, channels, state=ctx.state,
+            state_outputs='dense' if first else False)
         return grad_background, grad_vertices, grad_vertex_colors, None, None, None, None  # None wrt faces
 
 

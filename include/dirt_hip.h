@@ -57,6 +57,14 @@ extern "C" {
                                     not more efficient to render these in the forward pass and return them
                                     in separate outputs").  The state is caller-owned memory; the library
                                     stays stateless.  Results are identical with or without the flag. */
+#define DIRT_FLAG_DENSE_FROM_STATE 8u /* backward, with DIRT_FLAG_REUSE_STATE and dense caller tensors for grad_vertices /
+                                    grad_vertex_colors: sum the vertex gradients in the accumulators the forward pass
+                                    cleared inside the state (one interleaved row per vertex: what the float atomics are
+                                    fast on) and copy them out into the caller's dense [B,V,4] / [B,V,C] tensors with one
+                                    more launch -- what csrc/rasterise_grad_egl.cpp:381-391 allocates as the op's outputs.
+                                    Valid for ONE backward call per forward (the accumulators are not cleared again);
+                                    without the flag dense outputs are cleared and added into directly, any number of
+                                    times.  Results agree to summation order. */
 
 #define DIRT_FLAG_TILES_LARGE 0x200u /* pin the forward / visibility kernels' tile shape instead of letting the library
                                        choose it from the frame size and the face density: 32x32 pixel tiles ... */

@@ -373,6 +373,28 @@ def test_channel_group_passes(gpu, oracle, C):
                 assert np.array_equal(dbg.cpu().numpy(), ow['debug_thingy']), 'C=%d debug_thingy' % C
             parity.grads_close(gv, gvc, ow, 'C=%d flags=%d' % (C, flags), tol=5e-6)
 
+@pytest.mark.parametrize('C', [1, 3, 4, 5, 16])
+def test_dense_outputs_from_the_state(gpu, oracle, C):
+    """DIRT_FLAG_DENSE_FROM_STATE (what the autograd path uses): the gradients are summed in the state's interleaved
+    accumulators and copied out into dense tensors by the same call -- dense, contiguous, and equal to the strided views
+    the plain REUSE_STATE call returns (same kernel, same accumulators: bit for bit up to the atomics' order) and to the
+    oracle.  Without REUSE_STATE the flag is ignored."""
+    H, W = 75, 100
+    s = scenes.batch_scene(120, H, W, C, seeds=[5, 6, 7], r_lo=0.03, r_hi=0.3)
+    d = {k: _t(s[k], gpu) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
+    want = oracle.forward(s['background'], s['vertices'], s['vertex_colors'], s['faces'])
+    ow = oracle.backward(s['vertices'], s['faces'], want, s['grad_pixels'])
+    px, state = ops._op_rasterise(d['background'], d['vertices'], d['vertex_colors'], d['faces'], H, W, C, keep_state=True)
+    gb, gv, gvc, _ = ops._op_rasterise_grad(d['vertices'], d['faces'], px, d['grad_pixels'], H, W, C, state=state, state_outputs='dense')
+    assert gv.is_contiguous() and gvc.is_contiguous() and gv.shape == (3, s['vertices'].shape[1], 4) and gvc.shape[-1] == C
+    assert gv.data_ptr() < state.data_ptr() or gv.data_ptr() >= state.data_ptr() + state.numel()   # not a view of the state
+    assert np.array_equal(gb.cpu().numpy().view(np.uint32), ow['grad_background'].view(np.uint32))
+    parity.grads_close(gv, gvc, ow, 'dense from state, C=%d' % C, tol=5e-6)
+    from dirt_amd import _lib
+    gb2, gv2, gvc2, _ = ops._op_rasterise_grad(d['vertices'], d['faces'], px, d['grad_pixels'], H, W, C, flags=_lib.FLAG_DENSE_FROM_STATE)
+    parity.grads_close(gv2, gvc2, ow, 'flag without a state, C=%d' % C, tol=5e-6)
+
+
 def test_stream_handle_fallback_and_device_guard(gpu, oracle, monkeypatch):
     """The wrappers take the current stream's handle from torch's C binding where it exists and guard the device only
     when it is not current (host-side cost); the public-API fallbacks of both must give the same result."""
