@@ -91,6 +91,8 @@ CONFIGS = {
     'K3-384': (10000, 384, 384, 4, 0, 0.005, 0.04),     # in-between frame sizes: where the kernels' tile shapes switch
     'K3-512': (10000, 512, 512, 4, 0, 0.005, 0.04),
     'K3-768': (10000, 768, 768, 4, 0, 0.005, 0.04),
+    'K3-3ch': (10000, 1024, 1024, 3, 0, 0.005, 0.04),    # the headline mesh with an RGB / a one-channel image (the reference op's own channel counts)
+    'K3-1ch': (10000, 1024, 1024, 1, 0, 0.005, 0.04),
     'K2-cube': (12, 256, 256, 3, 0, 0.2, 0.6),           # a dozen large triangles at K2's frame (the cube itself: scenes.cube_scene)
     'K5': (50000, 2048, 2048, 16, 1, 0.002, 0.018),
     'K5-3ch': (50000, 2048, 2048, 3, 1, 0.002, 0.018),   # K5's mesh with an RGB image (what deferred shading filters)

@@ -21,6 +21,7 @@ for cfg in K3-256 K3-2048 K5; do
   python bench.py --config $cfg --steps 100 --warmup 20 --no-cpu-baseline > $OUT/bench_$cfg.json 2>> $OUT/bench.log
 done
 python bench.py --scenes-per-gpu 8 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_K3x8.json 2>> $OUT/bench.log
+for cfg in K3-3ch K3-1ch; do python bench.py --config $cfg --steps 100 --warmup 20 --no-cpu-baseline --traffic off > $OUT/bench_$cfg.json 2>> $OUT/bench.log; done
 python bench.py --scenes-per-gpu 64 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_K4x1.json 2>> $OUT/bench.log
 # kernel trace of the small-frame step (the one-pixel-per-lane gradient kernel) and of K5
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_K3-256 -o trace -- python tools/prof_run.py K3-256 50 > /dev/null 2>&1
