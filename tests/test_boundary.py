@@ -36,6 +36,23 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.dirt_abi_version() == 2
 
 
+def test_python_flag_constants_match_the_header():
+    """dirt_amd/_lib.py restates the DIRT_FLAG_* bits of include/dirt_hip.h: every flag of the header has its Python
+    constant with the same value, and no two flags share a bit."""
+    import re
+    from dirt_amd import _lib
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'dirt_hip.h')).read()
+    flags = {m.group(1): int(m.group(2), 0) for m in re.finditer(r'#define DIRT_FLAG_(\w+)\s+(0x[0-9a-fA-F]+|\d+)u', header)}
+    assert len(flags) >= 11
+    for name, value in flags.items():
+        assert getattr(_lib, 'FLAG_' + name) == value, name
+    assert len(set(flags.values())) == len(flags)
+    bits = 0
+    for v in flags.values():
+        assert v & (v - 1) == 0 and not (bits & v), 'flags are single, distinct bits'
+        bits |= v
+
+
 def test_header_cites_the_reference_interfaces():
     text = open(os.path.join(ROOT, 'include', 'dirt_hip.h')).read()
     for cite in ('csrc/rasterise_egl.cpp:32-51', 'csrc/rasterise_egl.cpp:276-407', 'csrc/rasterise_grad_egl.cpp:33-53',
