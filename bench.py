@@ -83,6 +83,9 @@ def main():
                          'pays), as one captured hipGraph replayed per step, or whichever a short calibration finds faster; both are '
                          'reported either way (ms_per_step_eager / ms_per_step_graph)')
     ap.add_argument('--flags', type=lambda x: int(x, 0), default=0, help='extra DIRT_FLAG_* bits for every call (kernel-shape experiments)')
+    ap.add_argument('--state-outputs', action='store_true',
+                    help='round 4\'s headline: vertex gradients left in the state\'s interleaved accumulators (strided views) instead of the '
+                         'op\'s dense contract outputs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the short K3-256 / K3-2048 legs')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline time budget')
@@ -141,8 +144,10 @@ def main():
         flags |= args.flags
         # exactly what torch.autograd does through dirt_amd.rasterise_batch: the forward leaves its
         # set-up records + visibility in a private state buffer, the backward consumes it
-        px, state = ops._op_rasterise(bg, v, vc, f, H, W, C, flags=flags, keep_state=True)
-        return ops._op_rasterise_grad(v, f, px, g, H, W, C, flags=flags, state=state)
+        # ... and its launch clears the DENSE grad_vertices [B,V,4] / grad_vertex_colors [B,V,C] that the backward call adds into
+        # and returns: the RasteriseGrad op's contract outputs (csrc/rasterise_grad_egl.cpp:381-391), no copy-out launch
+        px, state = ops._op_rasterise(bg, v, vc, f, H, W, C, flags=flags, keep_state=True, dense_grads=not args.state_outputs)
+        return ops._op_rasterise_grad(v, f, px, g, H, W, C, flags=flags, state=state, state_outputs=True if args.state_outputs else 'dense')
 
     def barrier():
         if distributed:
@@ -256,8 +261,8 @@ def main():
             bg2, v2, vc2, f2, g2 = (t(b2[k]) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels'))
 
             def step2():
-                px2, st2 = ops._op_rasterise(bg2, v2, vc2, f2, H2, W2, C2, flags=args.flags, keep_state=True)
-                return ops._op_rasterise_grad(v2, f2, px2, g2, H2, W2, C2, flags=args.flags, state=st2)
+                px2, st2 = ops._op_rasterise(bg2, v2, vc2, f2, H2, W2, C2, flags=args.flags, keep_state=True, dense_grads=True)
+                return ops._op_rasterise_grad(v2, f2, px2, g2, H2, W2, C2, flags=args.flags, state=st2, state_outputs='dense')
 
             ms2 = sorted(event_region(step2, 100) for _ in range(3))[1]
             by2 = algorithmic_bytes(H2 * W2, b2['vertices'].shape[1], F2, C2)
@@ -459,6 +464,9 @@ def main():
             'dtype': 'f32 (f64 edge functions)', 'data': 'synthetic',
             'config': {'workload': '%s: rand_mesh F=%d at %dx%dx%d, %d scene(s) per GPU, forward+backward'
                                    % (args.config, F, H, W, C, spg),
+                       'outputs': 'strided views of the state\'s interleaved accumulators (--state-outputs)' if args.state_outputs else
+                                  'dense grad_background [B,H,W,C], grad_vertices [B,V,4], grad_vertex_colors [B,V,C] (the op\'s contract outputs; '
+                                  'cleared inside the forward launch, no copy-out launch)',
                        'scenes_per_gpu': spg, 'parallelism': 'batch-sharded x%d, no collective' % world + (' (DIRT_BENCH_SHARE_GPU: all ranks on ONE GPU over gloo, control-flow test only)' if share_gpu else ''),
                        'launch': 'one captured hipGraph replayed per step' if use_graph else 'eager (Python wrapper + C ABI per step)'},
             'ranks_seen': ranks_seen,

@@ -10,12 +10,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DIRT_AMD_LIBRARY') or os.path.join(_HERE, 'libdirt_hip.so')  # override: instrumented builds (tools/)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 FLAG_Q1_INTENDED = 1
 FLAG_KEEP_STATE = 2
 FLAG_REUSE_STATE = 4
 FLAG_DENSE_FROM_STATE = 8   # backward: sum in the state's interleaved accumulators, copy out into the caller's dense tensors
+FLAG_OUTPUTS_CLEARED = 0x10  # backward: the dense outputs are the ones dirt_rasterise_forward_train cleared (checked by the library)
 FLAG_PROFILE = 0x100
 FLAG_TILES_LARGE = 0x200
 FLAG_TILES_SMALL = 0x400
@@ -23,6 +24,8 @@ FLAG_SHARED_FACES = 0x800
 FLAG_GRAD_ROWS = 0x1000    # gradient kernel: every 8x8 block walks its own faces (default for small frames)
 FLAG_GRAD_PAIRS = 0x2000   # ... or pairs of blocks share a face (default otherwise)
 FLAG_GRAD_SMALL = 0x4000   # ... or the one-pixel-per-lane kernel on 16x16 tiles (default for small frames with 1, 3 or 4 channels)
+FLAG_GRAD_PX2 = 0x8000    # ... or the two-pixels-per-lane kernel on 32x16 tiles (1, 3, 4 channels)
+FLAG_GRAD_PX4 = 0x10000   # ... or the four-pixels-per-lane kernel where the library would choose px2
 TEX_CLAMP = 1
 TEX_NEAREST = 2
 
@@ -34,7 +37,7 @@ E_HIP = -4
 _lib = None
 
 # every symbol include/dirt_hip.h declares (tests/test_boundary.py checks header <-> library)
-SYMBOLS = ('dirt_abi_version', 'dirt_last_error', 'dirt_workspace_bytes', 'dirt_rasterise_forward',
+SYMBOLS = ('dirt_abi_version', 'dirt_last_error', 'dirt_workspace_bytes', 'dirt_rasterise_forward', 'dirt_rasterise_forward_train',
            'dirt_rasterise_backward', 'dirt_rasterise_visibility', 'dirt_state_grad_buffers', 'dirt_profile_count',
            'dirt_profile_name',
            'dirt_profile_read', 'dirt_profile_reset', 'dirt_texture_sample_forward', 'dirt_texture_sample_backward',
@@ -66,6 +69,8 @@ def load():
     lib.dirt_workspace_bytes.restype = sz
     lib.dirt_rasterise_forward.argtypes = [fp, fp, fp, ip, fp, i, i, i, i, i, i, vp, sz, u, vp]
     lib.dirt_rasterise_forward.restype = i
+    lib.dirt_rasterise_forward_train.argtypes = [fp, fp, fp, ip, fp, fp, fp, i, i, i, i, i, i, vp, sz, u, vp]
+    lib.dirt_rasterise_forward_train.restype = i
     lib.dirt_rasterise_backward.argtypes = [fp, ip, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, vp, sz, u, vp]
     lib.dirt_rasterise_backward.restype = i
     lib.dirt_rasterise_visibility.argtypes = [fp, ip, ip, i, i, i, i, i, vp, sz, u, vp]

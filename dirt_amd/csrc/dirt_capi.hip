@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <initializer_list>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 #include "../../include/dirt_hip.h"
 #include "dirt_launch.h"
@@ -85,6 +87,55 @@ void drain_profile()
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- which gradient outputs a forward call has pre-cleared (host-side bookkeeping only) ---------------------------
+// A KEEP_STATE forward clears, inside its launch, the buffers the backward pass will add into: the interleaved accumulators
+// of the state, or (dirt_rasterise_forward_train) the caller's dense grad_vertices / grad_vertex_colors.  That is valid for
+// ONE backward call.  Instead of trusting the caller with that (round 4: a second backward with DIRT_FLAG_DENSE_FROM_STATE
+// silently returned doubled gradients), the library remembers per workspace address what is still "armed": a backward call
+// that finds its outputs armed consumes them and launches nothing to clear; one that does not -- a second backward over the
+// same forward, other tensors than the forward was given, a record that was evicted -- clears them itself with one more
+// launch.  Either way every backward call returns the gradients of that call alone.  No device state; the table is bounded.
+struct Armed {
+    const void* gv = nullptr;    // dense outputs cleared by the forward, still untouched
+    const void* gvc = nullptr;
+    bool acc = false;            // the state's own accumulators are cleared and untouched
+    unsigned long long tick = 0;
+};
+std::mutex g_armed_mu;
+std::unordered_map<const void*, Armed> g_armed;
+unsigned long long g_armed_tick = 0;
+constexpr size_t ARMED_CAP = 4096;
+
+void armed_set(const void* ws, const void* gv, const void* gvc, bool acc)
+{
+    std::lock_guard<std::mutex> lock(g_armed_mu);
+    if (!gv && !gvc && !acc) { g_armed.erase(ws); return; }
+    if (g_armed.size() >= ARMED_CAP && !g_armed.count(ws)) {   // drop the older half: a lost record only costs a clearing launch
+        const unsigned long long cut = g_armed_tick - ARMED_CAP / 2;
+        for (auto it = g_armed.begin(); it != g_armed.end();) it = it->second.tick < cut ? g_armed.erase(it) : std::next(it);
+    }
+    Armed a; a.gv = gv; a.gvc = gvc; a.acc = acc; a.tick = ++g_armed_tick;
+    g_armed[ws] = a;
+}
+bool armed_take_dense(const void* ws, const void* gv, const void* gvc)
+{
+    std::lock_guard<std::mutex> lock(g_armed_mu);
+    auto it = g_armed.find(ws);
+    if (it == g_armed.end() || !gv || it->second.gv != gv || it->second.gvc != gvc) return false;
+    it->second.gv = it->second.gvc = nullptr;
+    if (!it->second.acc) g_armed.erase(it);
+    return true;
+}
+bool armed_take_acc(const void* ws)
+{
+    std::lock_guard<std::mutex> lock(g_armed_mu);
+    auto it = g_armed.find(ws);
+    if (it == g_armed.end() || !it->second.acc) return false;
+    it->second.acc = false;
+    if (!it->second.gv) g_armed.erase(it);
+    return true;
+}
 
 struct Workspace {
     size_t recs_off, boxes_off, cells_off, entries_off, state_a_off, state_b_off, gv_off, gvc_off, total;
@@ -224,18 +275,17 @@ size_t dirt_workspace_bytes(int B, int V, int F, int H, int W, int C)
     return carve(B, V, F, H, W, C).total;
 }
 
-int dirt_rasterise_forward(const float* background, const float* vertices, const float* vertex_colors,
-                           const int32_t* faces, float* pixels, int B, int V, int F, int H, int W, int C,
-                           void* workspace, size_t workspace_bytes, unsigned flags, void* stream_)
+static int forward_impl(const char* who, const float* background, const float* vertices, const float* vertex_colors,
+                        const int32_t* faces, float* pixels, float* grad_vertices, float* grad_vertex_colors, int B, int V, int F,
+                        int H, int W, int C, void* workspace, size_t workspace_bytes, unsigned flags, void* stream_)
 {
-    const char* who = "dirt_rasterise_forward";
     int rc = check_sizes(who, B, V, F, H, W, C);
     if (rc) return rc;
     if (B == 0) return DIRT_OK;
     if (!background || !pixels) return fail(DIRT_E_INVALID_ARGUMENT, "%s: background / pixels is NULL", who);
     if ((V > 0 && (!vertices || !vertex_colors)) || (F > 0 && !faces))
         return fail(DIRT_E_INVALID_ARGUMENT, "%s: vertices / vertex_colors / faces is NULL", who);
-    rc = check_aligned(who, {background, vertices, vertex_colors, faces, pixels});
+    rc = check_aligned(who, {background, vertices, vertex_colors, faces, pixels, grad_vertices, grad_vertex_colors});
     if (rc) return rc;
     const Workspace w = carve(B, V, F, H, W, C);
     rc = check_workspace(who, w, workspace, workspace_bytes);
@@ -250,17 +300,46 @@ int dirt_rasterise_forward(const float* background, const float* vertices, const
     }
     dirt::RasterParams p = raster_params(c, g, C, flags);
     p.background = background; p.vertex_colors = vertex_colors; p.pixels = pixels;
+    const bool dense = grad_vertices != nullptr && grad_vertex_colors != nullptr && V > 0;
     if (flags & DIRT_FLAG_KEEP_STATE) {
         p.state_a = c.state_a; p.state_b = c.state_b;
-        // pre-clear the backward pass's accumulators (dirt_state_grad_buffers), a side job of the raster kernel's workgroups
-        p.zero_b = c.gv;  p.zero_b_bytes = sizeof(float) * (size_t)B * V * w.acc_stride;
+        // pre-clear what the backward pass will add into, a side job of the raster kernel's workgroups: the caller's dense
+        // gradient tensors (dirt_rasterise_forward_train), or the interleaved accumulators inside the state
+        if (dense) {
+            p.zero_b = grad_vertices;      p.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
+            p.zero_c = grad_vertex_colors; p.zero_c_bytes = sizeof(float) * (size_t)B * V * C;
+        } else {
+            p.zero_b = c.gv;  p.zero_b_bytes = sizeof(float) * (size_t)B * V * w.acc_stride;
+        }
     }
     {
         Scope sc(prof, SLOT_RASTER_FWD, stream);
         HIP_TRY(who, dirt::launch_raster(p, B, false, stream));
     }
+    if (flags & DIRT_FLAG_KEEP_STATE) armed_set(workspace, dense ? grad_vertices : nullptr, dense ? grad_vertex_colors : nullptr, !dense);
+    else armed_set(workspace, nullptr, nullptr, false);
     g_last_error[0] = 0;
     return DIRT_OK;
+}
+
+int dirt_rasterise_forward(const float* background, const float* vertices, const float* vertex_colors,
+                           const int32_t* faces, float* pixels, int B, int V, int F, int H, int W, int C,
+                           void* workspace, size_t workspace_bytes, unsigned flags, void* stream_)
+{
+    return forward_impl("dirt_rasterise_forward", background, vertices, vertex_colors, faces, pixels, nullptr, nullptr, B, V, F, H, W, C,
+                        workspace, workspace_bytes, flags, stream_);
+}
+
+int dirt_rasterise_forward_train(const float* background, const float* vertices, const float* vertex_colors,
+                                 const int32_t* faces, float* pixels, float* grad_vertices, float* grad_vertex_colors,
+                                 int B, int V, int F, int H, int W, int C, void* workspace, size_t workspace_bytes,
+                                 unsigned flags, void* stream_)
+{
+    const char* who = "dirt_rasterise_forward_train";
+    if (B > 0 && V > 0 && (!grad_vertices || !grad_vertex_colors))
+        return fail(DIRT_E_INVALID_ARGUMENT, "%s: grad_vertices / grad_vertex_colors is NULL", who);
+    return forward_impl(who, background, vertices, vertex_colors, faces, pixels, grad_vertices, grad_vertex_colors, B, V, F, H, W, C,
+                        workspace, workspace_bytes, flags | DIRT_FLAG_KEEP_STATE, stream_);
 }
 
 int dirt_rasterise_visibility(const float* vertices, const int32_t* faces, int32_t* face_id, int B, int V, int F,
@@ -328,14 +407,21 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
     const bool unpack = (flags & DIRT_FLAG_REUSE_STATE) && (flags & DIRT_FLAG_DENSE_FROM_STATE) && !own_outputs;
     const bool state_outputs = own_outputs || unpack;
     if (flags & DIRT_FLAG_REUSE_STATE) {
-        // records + visibility were left in this workspace by the forward pass; so were cleared gradient
-        // accumulators: if the caller's outputs ARE those nothing is left to do
-        if (!state_outputs) {
+        // records + visibility were left in this workspace by the forward pass; so were cleared gradient accumulators (or
+        // cleared dense outputs: dirt_rasterise_forward_train).  Whatever this call adds into is taken if it is still armed
+        // (cleared by that forward, untouched since) and cleared here otherwise: every call returns its own gradients.
+        if (state_outputs) {
+            if (!armed_take_acc(workspace)) {
+                Scope sc(prof, SLOT_GEOMETRY, stream);
+                HIP_TRY(who, dirt::launch_zero(c.gv, sizeof(float) * (size_t)B * V * w.acc_stride, nullptr, 0, stream));
+            }
+        } else if (!((flags & DIRT_FLAG_OUTPUTS_CLEARED) && armed_take_dense(workspace, grad_vertices, grad_vertex_colors))) {
             Scope sc(prof, SLOT_GEOMETRY, stream);
             HIP_TRY(who, dirt::launch_zero(grad_vertices, sizeof(float) * (size_t)B * V * 4, grad_vertex_colors,
                                            sizeof(float) * (size_t)B * V * C, stream));
         }
     } else {
+        armed_set(workspace, nullptr, nullptr, false);   // the state is rebuilt below; its accumulators are not cleared
         const dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
         {
             Scope sc(prof, SLOT_GEOMETRY, stream);

@@ -60,31 +60,6 @@ extern "C" void dirt_debug_set_trace_grad(void* p)
 #define GCOUNT(i, v) do {} while (0)
 #endif
 
-typedef unsigned long long lanemask;   // one bit per lane of the wave, wave-uniform (a scalar register pair)
-typedef float float2v __attribute__((ext_vector_type(2)));   // a register pair for the packed fp32 instructions (v_pk_fma_f32)
-
-// (s, s) * b [+ c] in one packed instruction.  op_sel_hi:[0,1,1] makes both halves take their first factor from the LOW
-// register of the first operand's pair, so the scalar needs no copy into a second register (the compiler, given a
-// splat, emits a v_mov per use); the pair's high register is never read.
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wuninitialized"
-__device__ __forceinline__ float2v pk_fma_scalar(float s, float2v b, float2v c)
-{
-    float2v a;
-    a.x = s;
-    float2v d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ float2v pk_mul_scalar(float s, float2v b)
-{
-    float2v a;
-    a.x = s;
-    float2v d;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-#pragma clang diagnostic pop
 
 constexpr int GT = 32;                  // tile side (pixels)
 constexpr int GTHREADS = 256;           // 4 waves: wave w owns rows 8w .. 8w+7; a DPP row of 16 lanes owns an 8 x 8 block of them
@@ -990,6 +965,15 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
         if (p.flags & DIRT_FLAG_GRAD_SMALL) small = small_ok;
         if (p.flags & (DIRT_FLAG_GRAD_ROWS | DIRT_FLAG_GRAD_PAIRS)) small = false;
         if (small) return launch_grad_small(p, stream);
+    }
+    {
+        // two pixels per lane (dirt_grad_px2.hip): twice the waves, half the chain each -- frames of more than one workgroup
+        // per compute unit with 1, 3 or 4 channels
+        const bool px2_ok = p.C == 1 || p.C == 3 || (p.C == 4 && p.pixels_aligned16);
+        bool px2 = px2_ok && !few_tiles;
+        if (p.flags & DIRT_FLAG_GRAD_PX2) px2 = px2_ok;
+        if (p.flags & (DIRT_FLAG_GRAD_ROWS | DIRT_FLAG_GRAD_PAIRS | DIRT_FLAG_GRAD_PX4)) px2 = false;
+        if (px2) return launch_grad_px2(p, stream);
     }
     bool rows = few_tiles && density >= 48;
     if (p.flags & DIRT_FLAG_GRAD_ROWS) rows = true;

@@ -71,6 +71,32 @@ __device__ __forceinline__ void write_debug(float* __restrict__ debug_thingy, co
     }
 }
 
+typedef unsigned long long lanemask;   // one bit per lane of the wave, wave-uniform (a scalar register pair)
+typedef float float2v __attribute__((ext_vector_type(2)));   // a register pair for the packed fp32 instructions (v_pk_fma_f32)
+
+// (s, s) * b [+ c] in one packed instruction.  op_sel_hi:[0,1,1] makes both halves take their first factor from the LOW
+// register of the first operand's pair, so the scalar needs no copy into a second register (the compiler, given a
+// splat, emits a v_mov per use); the pair's high register is never read.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wuninitialized"
+__device__ __forceinline__ float2v pk_fma_scalar(float s, float2v b, float2v c)
+{
+    float2v a;
+    a.x = s;
+    float2v d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float2v pk_mul_scalar(float s, float2v b)
+{
+    float2v a;
+    a.x = s;
+    float2v d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+#pragma clang diagnostic pop
+
 struct Float3 { float x, y, z; };   // three channels of a pixel: one 12-byte load / store (4-byte aligned)
 
 // Loads / stores at a 32-bit byte offset from a wave-uniform base: the address stays "scalar base + vector offset"

@@ -97,5 +97,6 @@ hipError_t launch_geometry(const GeomParams& g, hipStream_t stream);
 hipError_t launch_raster(const RasterParams& p, int B, bool visibility_only, hipStream_t stream);
 hipError_t launch_grad(const GradParams& p, hipStream_t stream);
 hipError_t launch_grad_small(const GradParams& p, hipStream_t stream);  // dirt_grad_small.hip; p as filled by launch_grad
+hipError_t launch_grad_px2(const GradParams& p, hipStream_t stream);    // dirt_grad_px2.hip (two pixels per lane, 32 x 16 tiles); p as filled by launch_grad
 
 }  // namespace dirt

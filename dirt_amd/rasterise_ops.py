@@ -167,14 +167,17 @@ def _dense16(t):
 
 
 def _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels, flags=0, keep_state=False,
-                  state_channels=0):
+                  state_channels=0, dense_grads=False):
     """`_rasterise_module.rasterise` (dirt/rasterise_ops.py:81-85): the raw forward op, no autograd.
 
     With keep_state=True returns (pixels, state): `state` is a private workspace holding the set-up
     records and the visibility buffer, to be handed to `_op_rasterise_grad(..., state=state)` so the
     backward pass does not render again (DIRT_FLAG_KEEP_STATE / DIRT_FLAG_REUSE_STATE).  `state_channels`
     sizes the state for later backward calls with up to that many channels (deferred shading: the shaded
-    image need not have the G-buffer's channel count)."""
+    image need not have the G-buffer's channel count).  `dense_grads` (with keep_state): the forward launch also
+    clears the DENSE grad_vertices / grad_vertex_colors tensors of the coming backward call
+    (dirt_rasterise_forward_train: the RasteriseGrad op's outputs, csrc/rasterise_grad_egl.cpp:381-391); they ride on
+    the state until `_op_rasterise_grad(..., state_outputs='dense')` takes them."""
     lib = _lib.load()
     _check_forward_shapes(background, vertices, vertex_colors, faces, height, width, channels)
     dev = _require_gpu(background, vertices, vertex_colors, faces)
@@ -183,6 +186,7 @@ def _op_rasterise(background, vertices, vertex_colors, faces, height, width, cha
     if faces.dim() == 2:
         flags |= _lib.FLAG_SHARED_FACES
     pixels = torch.empty_like(background)
+    grads = None
     with _on_device(dev):
         nbytes = _workspace_bytes(lib, B, V, F, height, width, channels)
         if keep_state:
@@ -196,11 +200,19 @@ def _op_rasterise(background, vertices, vertex_colors, faces, height, width, cha
             flags |= _lib.FLAG_KEEP_STATE
         else:
             ws = _workspace(dev, nbytes)
-        _lib.check(lib.dirt_rasterise_forward(
-            background.data_ptr(), vertices.data_ptr(), vertex_colors.data_ptr(), faces.data_ptr(), pixels.data_ptr(),
-            B, V, F, height, width, channels, ws.data_ptr(), ws.numel(), flags, _stream_handle(dev)))
+        if keep_state and dense_grads and B * V > 0:
+            grads = (torch.empty_like(vertices), torch.empty((B, V, channels), dtype=torch.float32, device=dev))
+            _lib.check(lib.dirt_rasterise_forward_train(
+                background.data_ptr(), vertices.data_ptr(), vertex_colors.data_ptr(), faces.data_ptr(), pixels.data_ptr(),
+                grads[0].data_ptr(), grads[1].data_ptr(),
+                B, V, F, height, width, channels, ws.data_ptr(), ws.numel(), flags, _stream_handle(dev)))
+        else:
+            _lib.check(lib.dirt_rasterise_forward(
+                background.data_ptr(), vertices.data_ptr(), vertex_colors.data_ptr(), faces.data_ptr(), pixels.data_ptr(),
+                B, V, F, height, width, channels, ws.data_ptr(), ws.numel(), flags, _stream_handle(dev)))
     if keep_state:
         ws._dirt_channels = channels   # the layout of the state's gradient accumulators depends on the channel count
+        ws._dirt_grads = grads         # dense gradient outputs this forward cleared (one backward call may take them)
     return (pixels, ws) if keep_state else pixels
 
 
@@ -212,8 +224,9 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
     `state`: the workspace a keep_state forward of the same vertices / faces / frame left behind; the call then
     neither sets up nor renders again.  With state_outputs=True (one backward per forward: autograd) the vertex
     gradients accumulate in the buffers that forward pre-cleared inside the state and the returned tensors are
-    views of it; with state_outputs='dense' they accumulate there too and the library copies them out into fresh DENSE
-    tensors with one more launch (DIRT_FLAG_DENSE_FROM_STATE: what the autograd path hands back); with
+    views of it; with state_outputs='dense' the call returns DENSE tensors, the op's contract (csrc/rasterise_grad_egl.cpp:381-391):
+    the ones a `dense_grads` forward cleared in its own launch, added into directly (DIRT_FLAG_OUTPUTS_CLEARED: what the autograd
+    path and bench.py use), or else fresh ones that receive a copy of the state's accumulators (DIRT_FLAG_DENSE_FROM_STATE); with
     state_outputs=False they are fresh tensors, cleared and added into directly, so a state can serve any number of
     backward calls (deferred shading: one for the shaded image, one for the G-buffer)."""
     lib = _lib.load()
@@ -233,7 +246,16 @@ def _op_rasterise_grad(vertices, faces, pixels, grad_pixels, height, width, chan
             state = None  # sized for fewer channels than this call has: render again
         if state is not None and getattr(state, '_dirt_channels', channels) != channels:
             state_outputs = False  # the accumulators inside the state were laid out (and cleared) for another channel count
-        if state is not None and (not state_outputs or state_outputs == 'dense'):
+        taken = None
+        if state is not None and state_outputs == 'dense' and getattr(state, '_dirt_grads', None) is not None:
+            taken, state._dirt_grads = state._dirt_grads, None   # the tensors that forward cleared: taken once
+            if tuple(taken[1].shape) != (B, V, channels):
+                taken = None
+        if taken is not None:
+            ws = state
+            flags |= _lib.FLAG_REUSE_STATE | _lib.FLAG_OUTPUTS_CLEARED
+            grad_vertices, grad_vertex_colors = taken
+        elif state is not None and (not state_outputs or state_outputs == 'dense'):
             ws = state
             flags |= _lib.FLAG_REUSE_STATE | (_lib.FLAG_DENSE_FROM_STATE if state_outputs == 'dense' else 0)
             grad_vertices = torch.empty_like(vertices)
@@ -296,7 +318,7 @@ class _Rasterise(torch.autograd.Function):
     def forward(ctx, background, vertices, vertex_colors, faces, height, width, channels):
         needs_grad = any(ctx.needs_input_grad[:3])
         if needs_grad:
-            pixels, state = _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels, keep_state=True)
+            pixels, state = _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels, keep_state=True, dense_grads=True)
         else:
             pixels, state = _op_rasterise(background, vertices, vertex_colors, faces, height, width, channels), None
         ctx.save_for_backward(vertices, faces, pixels)  # op.inputs[1], op.inputs[3], op.outputs[0]
@@ -315,10 +337,9 @@ class _Rasterise(torch.autograd.Function):
         # the reference's grad op is pure (csrc/rasterise_grad_egl.cu:244-250 clears its outputs on every call).
         first = not getattr(ctx, 'state_outputs_used', False)
         ctx.state_outputs_used = True
-        # the state's accumulators are interleaved (one row {x, y, z, w, colours} per vertex); autograd gets DENSE tensors,
-        # as the reference's op returns -- strided views would pin the whole state (records + 16 bytes per pixel) for as
-        # long as a gradient lives, make `.view(-1)` raise, and be cloned by AccumulateGrad anyway: the library copies them
-        # out itself (one launch inside the same call instead of two torch copies)
+        # autograd gets DENSE tensors, as the reference's op returns (csrc/rasterise_grad_egl.cpp:381-391): the ones the forward
+        # launch cleared (`dense_grads`), which the gradient kernel adds into directly -- a backward call is ONE launch.
+        # (Round 4 summed in the state's interleaved accumulators and copied them out with a second launch.)
         if grad_pixels.dtype != torch.float32:
             grad_pixels = grad_pixels.to(torch.float32)
         grad_background, grad_vertices, grad_vertex_colors, _ = _op_rasterise_grad(

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DIRT_ABI_VERSION 2
+#define DIRT_ABI_VERSION 3
 
 /* error codes */
 #define DIRT_OK 0
@@ -60,11 +60,19 @@ extern "C" {
 #define DIRT_FLAG_DENSE_FROM_STATE 8u /* backward, with DIRT_FLAG_REUSE_STATE and dense caller tensors for grad_vertices /
                                     grad_vertex_colors: sum the vertex gradients in the accumulators the forward pass
                                     cleared inside the state (one interleaved row per vertex: what the float atomics are
-                                    fast on) and copy them out into the caller's dense [B,V,4] / [B,V,C] tensors with one
+                                    fastest on) and copy them out into the caller's dense [B,V,4] / [B,V,C] tensors with one
                                     more launch -- what csrc/rasterise_grad_egl.cpp:381-391 allocates as the op's outputs.
-                                    Valid for ONE backward call per forward (the accumulators are not cleared again);
-                                    without the flag dense outputs are cleared and added into directly, any number of
-                                    times.  Results agree to summation order. */
+                                    Re-entrant since ABI 3: the library knows (host-side, per workspace address) whether the
+                                    accumulators are still as the forward left them and clears them itself when they are
+                                    not, so a second backward call over one forward returns that call's gradients, not the
+                                    sum of both.  Results agree to summation order. */
+#define DIRT_FLAG_OUTPUTS_CLEARED 0x10u /* backward, with DIRT_FLAG_REUSE_STATE: grad_vertices / grad_vertex_colors are the
+                                    very tensors dirt_rasterise_forward_train was given with this workspace, and nothing
+                                    has written to them since: skip the launch that clears them (the reference's
+                                    cudaMemsetAsync, csrc/rasterise_grad_egl.cu:244-250, happened inside the forward's
+                                    launch).  Checked against the library's host-side record of that forward: if the
+                                    record does not name these pointers, or a backward call has consumed it already, the
+                                    outputs are cleared as without the flag -- never added onto. */
 
 #define DIRT_FLAG_TILES_LARGE 0x200u /* pin the forward / visibility kernels' tile shape instead of letting the library
                                        choose it from the frame size and the face density: 32x32 pixel tiles ... */
@@ -79,6 +87,11 @@ extern "C" {
                                         32x32 tiles -- are at most 256 and the mesh has at least 96 faces per tile, counted
                                         over ALL faces of a scene, culled and off-screen ones included).  Same results to
                                         summation order */
+#define DIRT_FLAG_GRAD_PX2 0x8000u   /* ... or the two-pixels-per-lane gradient kernel on 32x16 tiles (channel counts 1, 3, 4:
+                                        twice the waves at half the instruction chain each; chosen by the library for frames
+                                        of more than 256 32x32 tiles).  Same results to summation order */
+#define DIRT_FLAG_GRAD_PX4 0x10000u  /* ... or the four-pixels-per-lane kernel (rows or pairs by the library's own rule) where
+                                        the library would choose the two-pixels-per-lane one */
 #define DIRT_FLAG_SHARED_FACES 0x800u /* `faces` is one [F,3] topology shared by all B scenes instead of [B,F,3] (the
                                         TODO of csrc/rasterise_egl.cpp:314).  Same flag on the
                                         forward, visibility and backward calls of one scene batch. */
@@ -115,6 +128,20 @@ size_t dirt_workspace_bytes(int B, int V, int F, int H, int W, int C);
 int dirt_rasterise_forward(const float *background, const float *vertices, const float *vertex_colors,
                            const int32_t *faces, float *pixels, int B, int V, int F, int H, int W, int C,
                            void *workspace, size_t workspace_bytes, unsigned flags, void *stream);
+
+/*
+ * Forward of a training step: dirt_rasterise_forward with DIRT_FLAG_KEEP_STATE that, in the same launch, also clears the
+ * DENSE gradient tensors the backward call will be given -- the RasteriseGrad op's outputs grad_vertices [B,V,4] and
+ * grad_vertex_colors [B,V,C] (csrc/rasterise_grad_egl.cpp:381-391), which the reference clears with cudaMemsetAsync at the
+ * start of its gradient op (csrc/rasterise_grad_egl.cu:244-250).  A following dirt_rasterise_backward with
+ * DIRT_FLAG_REUSE_STATE | DIRT_FLAG_OUTPUTS_CLEARED on the same workspace and the same two tensors then is ONE launch that
+ * adds straight into the op's contract outputs: no clearing launch, no copy out of the state.  (The state's own
+ * interleaved accumulators are NOT cleared by this call.)
+ */
+int dirt_rasterise_forward_train(const float *background, const float *vertices, const float *vertex_colors,
+                                 const int32_t *faces, float *pixels, float *grad_vertices, float *grad_vertex_colors,
+                                 int B, int V, int F, int H, int W, int C, void *workspace, size_t workspace_bytes,
+                                 unsigned flags, void *stream);
 
 /*
  * Backward.  Replaces the `RasteriseGrad` op: REGISTER_OP csrc/rasterise_grad_egl.cpp:33-53,

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(syms) == set(_lib.SYMBOLS), (syms, _lib.SYMBOLS)
     for s in syms:
         assert hasattr(lib, s), 'libdirt_hip.so does not export %s' % s
-    assert lib.dirt_abi_version() == 2
+    assert lib.dirt_abi_version() == 3
 
 
 def test_python_flag_constants_match_the_header():

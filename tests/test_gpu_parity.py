@@ -32,7 +32,8 @@ def _fwd_gpu(s, dev, flags=0):
 # only ever see the small shape, so the parity tests pin each shape in turn (DIRT_FLAG_TILES_*).
 # (the tile-shape flags of the forward kernels, each with one of the gradient kernel's face-loop shapes pinned as well)
 TILE_SHAPES = [pytest.param(0, id='auto'), pytest.param(0x200 | 0x2000, id='large-tiles'), pytest.param(0x400 | 0x1000, id='small-tiles'),
-               pytest.param(0x400 | 0x4000, id='small-tiles-px1')]
+               pytest.param(0x400 | 0x4000, id='small-tiles-px1'), pytest.param(0x200 | 0x8000, id='large-tiles-px2'),
+               pytest.param(0x10000, id='px4')]
 
 
 def _assert_grad_close(got, ow, key, what, index=None):
@@ -473,7 +474,7 @@ def test_misaligned_views_are_accepted(gpu, oracle):
 
 
 @pytest.mark.parametrize('C', [1, 3, 4, 5, 9, 10, 16])
-@pytest.mark.parametrize('shape', [pytest.param(0x2000, id='pairs'), pytest.param(0x1000, id='rows'), pytest.param(0x4000, id='px1')])
+@pytest.mark.parametrize('shape', [pytest.param(0x2000, id='pairs'), pytest.param(0x1000, id='rows'), pytest.param(0x4000, id='px1'), pytest.param(0x8000, id='px2')])
 def test_non_finite_grad_pixels_stay_with_their_own_face(gpu, oracle, C, shape):
     """The reference adds a pixel's terms to the vertices of that pixel's face only (csrc/rasterise_grad_egl.cu:140,228-230):
     a NaN / Inf in grad_pixels makes exactly those vertices' gradients non-finite.  The wave-level reductions here
