@@ -124,6 +124,7 @@ def main():
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)            # proof that RCCL sees every rank; outside the timed region
         ranks_seen = int(ones.item())
+        assert ranks_seen == world, 'RCCL all-reduce saw %d of %d ranks' % (ranks_seen, world)
 
     from dirt_amd import scenes, _lib, rasterise_ops as ops
     _lib.load()
@@ -250,25 +251,44 @@ def main():
     # thread wake-ups per backward(), which is most of what the autograd path costs over the raw ops at this step length
     with torch.autograd.set_multithreading_enabled(False):
         ms_per_step_autograd_1t = sorted(event_region(autograd_step, max(20, min(args.steps, 200))) for _ in range(3))[1]
+    # ... and the remedy that needs no switch: the same forward + backward captured once as a HIP graph
+    # (dirt_amd.GraphedStep: rasterise_batch -> backward(grad_pixels) recorded on fixed buffers, one hipGraphLaunch per step,
+    # dense gradients) -- what a static-shape training loop should call
+    ms_per_step_autograd_graphed = None
+    try:
+        from dirt_amd import GraphedStep
+        gstep = GraphedStep(bg_l.detach(), v_l.detach(), vc_l.detach(), f, grad_pixels=g)
+        ms_per_step_autograd_graphed = sorted(event_region(gstep, max(20, min(args.steps, 200))) for _ in range(3))[1]
+        del gstep
+    except Exception as e:   # reported, never fatal to the bench line
+        ms_per_step_autograd_graphed = 'failed: %s' % (str(e)[:100],)
     del bg_l, v_l, vc_l
 
     # ---- the other frame sizes BASELINE.json's north_star asks for (256^2 and 2048^2, same mesh): short legs, one scene ----
     other_configs = {}
-    if rank == 0 and world == 1 and args.config == 'K3' and not args.no_other_configs:
+    if args.config == 'K3' and not args.no_other_configs:
+        # (at N > 1 every rank renders its own scene of the leg at the same time, as in the headline: the figure is the
+        # max over ranks, the value the pixels of all ranks over it)
         for name in ('K3-256', 'K3-2048'):
             F2, H2, W2, C2, seed2, lo2, hi2 = scenes.CONFIGS[name]
-            b2 = scenes.batch_scene(F2, H2, W2, C2, [seed2], r_lo=lo2, r_hi=hi2)
+            b2 = scenes.batch_scene(F2, H2, W2, C2, [seed2 + rank], r_lo=lo2, r_hi=hi2)
             bg2, v2, vc2, f2, g2 = (t(b2[k]) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels'))
 
             def step2():
                 px2, st2 = ops._op_rasterise(bg2, v2, vc2, f2, H2, W2, C2, flags=args.flags, keep_state=True, dense_grads=True)
                 return ops._op_rasterise_grad(v2, f2, px2, g2, H2, W2, C2, flags=args.flags, state=st2, state_outputs='dense')
 
+            if distributed:
+                dist.barrier()
             ms2 = sorted(event_region(step2, 100) for _ in range(3))[1]
+            if distributed:
+                tm = torch.tensor([ms2], dtype=torch.float64, device=dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                ms2 = float(tm.item())
             by2 = algorithmic_bytes(H2 * W2, b2['vertices'].shape[1], F2, C2)
-            other_configs[name] = {'ms_per_step': ms2, 'value': H2 * W2 / ms2 / 1e3, 'unit': 'Mpixels/s', 'steps': 100,
+            other_configs[name] = {'ms_per_step': ms2, 'value': world * H2 * W2 / ms2 / 1e3, 'unit': 'Mpixels/s', 'steps': 100, 'n_gpus': world,
                                    'roofline_step_frac': by2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                   'workload': 'rand_mesh F=%d at %dx%dx%d, 1 scene, forward+backward' % (F2, H2, W2, C2)}
+                                   'workload': 'rand_mesh F=%d at %dx%dx%d, 1 scene per GPU, forward+backward, dense outputs' % (F2, H2, W2, C2)}
             del bg2, v2, vc2, f2, g2
 
     # ---- N > 1: the same per-GPU workload on rank 0 ALONE (every other rank idles at the barrier), so that the line
@@ -476,9 +496,11 @@ def main():
                       'ms_per_step_events_median: the same K steps between a HIP-event pair on the launch stream, no synchronisation '
                       'after the warm-up, median of 5 regions (SURVEY.md 8d); ms_per_step_autograd: dirt.rasterise_batch(...).backward() '
                       'with leaf tensors and dense gradients, event-timed; ..._engine_on_calling_thread: the same under '
-                      'torch.autograd.set_multithreading_enabled(False) (no hand-off to the per-device backward thread)',
+                      'torch.autograd.set_multithreading_enabled(False) (no hand-off to the per-device backward thread); ..._graphed: the same '
+                      'rasterise_batch -> backward captured once as a HIP graph (dirt_amd.GraphedStep), one graph launch per step',
             'ms_per_step_autograd': ms_per_step_autograd,
             'ms_per_step_autograd_engine_on_calling_thread': ms_per_step_autograd_1t,
+            'ms_per_step_autograd_graphed': ms_per_step_autograd_graphed,
             'other_configs': other_configs,
             'ms_per_step_eager': calib['eager_ms_per_step'], 'ms_per_step_graph': calib['graph_ms_per_step'],
             'launch_calibration': calib,

@@ -29,12 +29,23 @@ def hipcc_path():
     return 'hipcc'
 
 
-def needs_build():
+def _flags_stamp(extra_flags=()):
+    """What the objects were compiled with: a flag change must trigger a rebuild as a source change does."""
+    import hashlib
+    return hashlib.sha256(repr((HIPCC_FLAGS, sorted(PER_SOURCE_FLAGS.items()), list(extra_flags), SOURCES)).encode()).hexdigest()
+
+
+def needs_build(extra_flags=()):
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    try:
+        return open(os.path.join(OBJ_DIR, 'flags.sha256')).read().strip() != _flags_stamp(extra_flags)
+    except OSError:
+        return True
 
 
 # per-source flags.  dirt_grad.hip: the SLP vectoriser turns two of the four per-pixel barycentric triples into
@@ -47,7 +58,7 @@ OBJ_DIR = os.path.join(_HERE, 'csrc', '.obj')
 def build_library(force=False, verbose=False, extra_flags=(), out=None):
     """Compile every HIP source (one hipcc -c each, in parallel) and link them into one shared library.  Raises on failure.
     `out`: another path for the library (instrumented / experimental builds under tools/_bin: tools/variants.sh)."""
-    if out is None and not force and not needs_build():
+    if out is None and not force and not needs_build(extra_flags):
         return LIB_PATH
     lib_path = out or LIB_PATH
     obj_dir = OBJ_DIR if out is None else os.path.join(OBJ_DIR, os.path.basename(out))
@@ -60,15 +71,26 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None):
         if verbose:
             print(' '.join(cmd), file=sys.stderr)
         procs.append((cmd, obj, subprocess.Popen(cmd)))
-    objs = []
+    # every compiler is waited for before anything is raised (none is left running behind an exception), and the objects of
+    # failed compilations are removed so that no later link can pick up a stale or partial one
+    objs, failed = [], None
     for cmd, obj, pr in procs:
         if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
+            failed = failed or (pr.returncode, cmd)
+            try:
+                os.remove(obj)
+            except OSError:
+                pass
         objs.append(obj)
+    if failed:
+        raise subprocess.CalledProcessError(failed[0], failed[1])
     link = [hipcc_path(), '--offload-arch=gfx950', '-fPIC', '-shared'] + objs + ['-o', lib_path]
     if verbose:
         print(' '.join(link), file=sys.stderr)
     subprocess.check_call(link)
+    if out is None:
+        with open(os.path.join(obj_dir, 'flags.sha256'), 'w') as fh:
+            fh.write(_flags_stamp(extra_flags))
     return lib_path
 
 

@@ -842,12 +842,13 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
         //      float rounding), everything taken at the pixel whose fragment is used.  (fx, fy) are summed per such
         //      TARGET pixel -- own pixels in registers, neighbours through the inbox -- and fw is formed once per pixel. ----
         // Per pixel: the clip_w of each neighbour that would dilate into it -- another face (:86-89) that is closer (:165) --
-        // or 0; the attempt order of :186-193 is then two selects per pixel (by the parity dither) and two per channel
-        // group (by its axis), and "which neighbour, if any" two compares against 0.  A pixel's own fragment is the common
+        // or a NaN sentinel; the attempt order of :186-193 is then two selects per pixel (by the parity dither) and two per channel
+        // group (by its axis), and "which neighbour, if any" two self-compares.  A pixel's own fragment is the common
         // case and runs unconditionally (one rcp of its own clip_w per pixel); the neighbour's clip_w, its reciprocal and
         // the inbox address exist only for the few dilated lanes.  (Rounds 2-3 kept every predicate as a wave-wide lane
         // mask combined on the scalar unit: ~40 masks alive, moved through VGPRs by the compiler, and every pixel a chain
         // v_cmp -> s_and / s_or x 6 -> v_cndmask x 4; this form has 160 fewer scalar instructions per wave.)
+        const float NO_NEIGHBOUR = __builtin_nanf("");   // (a value no clip_w that passed `wo > w` can have: a qualifying neighbour with clip_w == +-0 still counts, as in :165)
         const bool pos0 = ((xs + y) & 1) == 0;   // pixel 0 tries +x / up first (:186-191)
         const float2v half_size = float2v{.5f * width_f, .5f * height_f};
 #pragma unroll
@@ -856,10 +857,10 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
             const int fl = j == 0 ? f_l : f_own[j - 1], fr = j == 3 ? f_r : f_own[j + 1];
             // (the pixel's own face as the state tile has it: an uncovered pixel, -1, differs from any face)
             const float wo = interior[j] ? w_own[j] : -INFINITY;   // pixels on the frame's border are never dilated (:155)
-            const float qL = ((fl != f_own[j]) & (wo > wl)) ? wl : 0.f;
-            const float qR = ((fr != f_own[j]) & (wo > wr)) ? wr : 0.f;
-            const float qU = ((f_up[j] != f_own[j]) & (wo > w_up[j])) ? w_up[j] : 0.f;
-            const float qD = ((f_dn[j] != f_own[j]) & (wo > w_dn[j])) ? w_dn[j] : 0.f;
+            const float qL = ((fl != f_own[j]) & (wo > wl)) ? wl : NO_NEIGHBOUR;
+            const float qR = ((fr != f_own[j]) & (wo > wr)) ? wr : NO_NEIGHBOUR;
+            const float qU = ((f_up[j] != f_own[j]) & (wo > w_up[j])) ? w_up[j] : NO_NEIGHBOUR;
+            const float qD = ((f_dn[j] != f_own[j]) & (wo > w_dn[j])) ? w_dn[j] : NO_NEIGHBOUR;
             const bool pos = (j & 1) ? !pos0 : pos0;   // first attempt towards +x / up (:191), else -x / down
             const float qx1 = pos ? qR : qL, qx2 = pos ? qL : qR, qy1 = pos ? qU : qD, qy2 = pos ? qD : qU;
             const float rcp_own = __builtin_amdgcn_rcpf(w_own[j]);
@@ -871,8 +872,8 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
                 // offsets are in GL buffer orientation (y up): tensor row = y - offset_y.
                 const bool hz = __builtin_amdgcn_inverse_ballot_w64(horiz_m[gi][j]);
                 const float q1 = hz ? qx1 : qy1, q2 = hz ? qx2 : qy2;
-                const bool first = q1 != 0.f;                 // the first attempt found its neighbour
-                const bool dilated = first | (q2 != 0.f);     // ... or the opposite one did (:192-193)
+                const bool first = q1 == q1;                  // the first attempt found its neighbour (not the NaN sentinel)
+                const bool dilated = first | (q2 == q2);      // ... or the opposite one did (:192-193)
                 if constexpr (DEBUG) {
                     if (cbase == 0 && gi == 0 && in_px[j]) write_debug(p.debug_thingy, p.grad_pixels, p.B, H, W, C, iib, y, xs + j, G0, dilated);
                 }
@@ -967,10 +968,18 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
         if (small) return launch_grad_small(p, stream);
     }
     {
-        // two pixels per lane (dirt_grad_px2.hip): twice the waves, half the chain each -- frames of more than one workgroup
-        // per compute unit with 1, 3 or 4 channels
+        // Two pixels per lane (dirt_grad_px2.hip: 32 x 16 tiles, twice the waves at half the chain each, 5-7 workgroups per
+        // compute unit).  Measured on MI355X (round 5, gradient kernel in us, HIP events, 10 000 faces, dense outputs):
+        //                          32x32 tiles    px2     4-pixel kernel
+        //   K3-768  (4 ch)             576        20.8        24.0       the 4-pixel grid leaves compute units with 2 or 3 workgroups
+        //   K3      (4 ch)            1024        27.1        26.4       one full round of the 4-pixel kernel: nothing to gain
+        //   K3-3ch                    1024        22.2        23.1       (64 VGPRs: seven workgroups per compute unit)
+        //   K3-1ch                    1024        20.6        18.9
+        //   K3-2048 (4 ch)            4096        72.9        68.2       rounds overlap by themselves; px2's extra atomics and instructions cost
+        // Rule: more than one workgroup per compute unit but less than a full round of the 4-pixel kernel; 3 channels up to a full round.
         const bool px2_ok = p.C == 1 || p.C == 3 || (p.C == 4 && p.pixels_aligned16);
-        bool px2 = px2_ok && !few_tiles;
+        const long long wgs32 = (long long)ntiles * p.B;
+        bool px2 = px2_ok && !few_tiles && (wgs32 < 1024 || (p.C == 3 && wgs32 <= 1024));
         if (p.flags & DIRT_FLAG_GRAD_PX2) px2 = px2_ok;
         if (p.flags & (DIRT_FLAG_GRAD_ROWS | DIRT_FLAG_GRAD_PAIRS | DIRT_FLAG_GRAD_PX4)) px2 = false;
         if (px2) return launch_grad_px2(p, stream);

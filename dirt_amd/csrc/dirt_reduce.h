@@ -38,7 +38,10 @@ __device__ __forceinline__ float pack_pair(float lo, float hi, bool upper)
 // asm block, so that the wait states a DPP operand needs behind the VALU instruction that wrote it (two) are paid once
 // per level -- one leading s_nop; inside the block every source was written at least two instructions earlier -- and not
 // once per pair (rounds 2-3: 18 s_nop per reduction, 154 per wave at K3).  The trailing s_nop covers whatever DPP
-// instruction the compiler places behind the block (it does not look inside inline assembly).
+// instruction the compiler places behind the block (it does not look inside inline assembly).  The in/out operands are
+// EARLY-CLOBBER ("+&v"): lo[i] is overwritten while hi[j] of later pairs is still to be read, so no hi[j] may share a register
+// with a lo[i] -- which the compiler would otherwise be free to arrange when both hold the same value (a padding zero in both
+// halves: tools/reduce_test.hip has that case).
 // bit 3 (lanes 8-15 of a row = banks 2, 3): lo + partner's lo everywhere, then hi + partner's hi in the upper banks.
 // bit 2 (banks 1, 3 are the upper lanes): banks 0, 2 take lo + lo of the lane four above (row_shl:4), banks 1, 3 take
 // hi + hi of the lane four below (row_shr:4).
@@ -79,7 +82,7 @@ __device__ __forceinline__ void level_bit3(float (&lo)[16], const float (&hi)[16
             "v_add_f32_dpp %15, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
             "v_add_f32_dpp %15, %31, %31 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
             "s_nop 1"
-        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]), "+v"(lo[8]), "+v"(lo[9]), "+v"(lo[10]), "+v"(lo[11]), "+v"(lo[12]), "+v"(lo[13]), "+v"(lo[14]), "+v"(lo[15])
+        : "+&v"(lo[0]), "+&v"(lo[1]), "+&v"(lo[2]), "+&v"(lo[3]), "+&v"(lo[4]), "+&v"(lo[5]), "+&v"(lo[6]), "+&v"(lo[7]), "+&v"(lo[8]), "+&v"(lo[9]), "+&v"(lo[10]), "+&v"(lo[11]), "+&v"(lo[12]), "+&v"(lo[13]), "+&v"(lo[14]), "+&v"(lo[15])
         : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]), "v"(hi[8]), "v"(hi[9]), "v"(hi[10]), "v"(hi[11]), "v"(hi[12]), "v"(hi[13]), "v"(hi[14]), "v"(hi[15]));
 }
 __device__ __forceinline__ void level_bit3(float (&lo)[12], const float (&hi)[12])
@@ -110,7 +113,7 @@ __device__ __forceinline__ void level_bit3(float (&lo)[12], const float (&hi)[12
             "v_add_f32_dpp %11, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
             "v_add_f32_dpp %11, %23, %23 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
             "s_nop 1"
-        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]), "+v"(lo[8]), "+v"(lo[9]), "+v"(lo[10]), "+v"(lo[11])
+        : "+&v"(lo[0]), "+&v"(lo[1]), "+&v"(lo[2]), "+&v"(lo[3]), "+&v"(lo[4]), "+&v"(lo[5]), "+&v"(lo[6]), "+&v"(lo[7]), "+&v"(lo[8]), "+&v"(lo[9]), "+&v"(lo[10]), "+&v"(lo[11])
         : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]), "v"(hi[8]), "v"(hi[9]), "v"(hi[10]), "v"(hi[11]));
 }
 __device__ __forceinline__ void level_bit3(float (&lo)[8], const float (&hi)[8])
@@ -133,7 +136,7 @@ __device__ __forceinline__ void level_bit3(float (&lo)[8], const float (&hi)[8])
             "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
             "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
             "s_nop 1"
-        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7])
+        : "+&v"(lo[0]), "+&v"(lo[1]), "+&v"(lo[2]), "+&v"(lo[3]), "+&v"(lo[4]), "+&v"(lo[5]), "+&v"(lo[6]), "+&v"(lo[7])
         : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]));
 }
 __device__ __forceinline__ void level_bit3(float (&lo)[6], const float (&hi)[6])
@@ -152,7 +155,7 @@ __device__ __forceinline__ void level_bit3(float (&lo)[6], const float (&hi)[6])
             "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
             "v_add_f32_dpp %5, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
             "s_nop 1"
-        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5])
+        : "+&v"(lo[0]), "+&v"(lo[1]), "+&v"(lo[2]), "+&v"(lo[3]), "+&v"(lo[4]), "+&v"(lo[5])
         : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]));
 }
 __device__ __forceinline__ void level_bit3(float (&lo)[4], const float (&hi)[4])
@@ -167,7 +170,7 @@ __device__ __forceinline__ void level_bit3(float (&lo)[4], const float (&hi)[4])
             "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
             "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
             "s_nop 1"
-        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3])
+        : "+&v"(lo[0]), "+&v"(lo[1]), "+&v"(lo[2]), "+&v"(lo[3])
         : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
 }
 __device__ __forceinline__ void level_bit2(float (&lo)[16], const float (&hi)[16])
@@ -206,7 +209,7 @@ __device__ __forceinline__ void level_bit2(float (&lo)[16], const float (&hi)[16
             "v_add_f32_dpp %15, %15, %15 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
             "v_add_f32_dpp %15, %31, %31 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
             "s_nop 1"
-        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]), "+v"(lo[8]), "+v"(lo[9]), "+v"(lo[10]), "+v"(lo[11]), "+v"(lo[12]), "+v"(lo[13]), "+v"(lo[14]), "+v"(lo[15])
+        : "+&v"(lo[0]), "+&v"(lo[1]), "+&v"(lo[2]), "+&v"(lo[3]), "+&v"(lo[4]), "+&v"(lo[5]), "+&v"(lo[6]), "+&v"(lo[7]), "+&v"(lo[8]), "+&v"(lo[9]), "+&v"(lo[10]), "+&v"(lo[11]), "+&v"(lo[12]), "+&v"(lo[13]), "+&v"(lo[14]), "+&v"(lo[15])
         : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]), "v"(hi[8]), "v"(hi[9]), "v"(hi[10]), "v"(hi[11]), "v"(hi[12]), "v"(hi[13]), "v"(hi[14]), "v"(hi[15]));
 }
 __device__ __forceinline__ void level_bit2(float (&lo)[12], const float (&hi)[12])
@@ -237,7 +240,7 @@ __device__ __forceinline__ void level_bit2(float (&lo)[12], const float (&hi)[12
             "v_add_f32_dpp %11, %11, %11 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
             "v_add_f32_dpp %11, %23, %23 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
             "s_nop 1"
-        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]), "+v"(lo[8]), "+v"(lo[9]), "+v"(lo[10]), "+v"(lo[11])
+        : "+&v"(lo[0]), "+&v"(lo[1]), "+&v"(lo[2]), "+&v"(lo[3]), "+&v"(lo[4]), "+&v"(lo[5]), "+&v"(lo[6]), "+&v"(lo[7]), "+&v"(lo[8]), "+&v"(lo[9]), "+&v"(lo[10]), "+&v"(lo[11])
         : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]), "v"(hi[8]), "v"(hi[9]), "v"(hi[10]), "v"(hi[11]));
 }
 __device__ __forceinline__ void level_bit2(float (&lo)[8], const float (&hi)[8])
@@ -260,7 +263,7 @@ __device__ __forceinline__ void level_bit2(float (&lo)[8], const float (&hi)[8])
             "v_add_f32_dpp %7, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
             "v_add_f32_dpp %7, %15, %15 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
             "s_nop 1"
-        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7])
+        : "+&v"(lo[0]), "+&v"(lo[1]), "+&v"(lo[2]), "+&v"(lo[3]), "+&v"(lo[4]), "+&v"(lo[5]), "+&v"(lo[6]), "+&v"(lo[7])
         : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]), "v"(hi[7]));
 }
 __device__ __forceinline__ void level_bit2(float (&lo)[6], const float (&hi)[6])
@@ -279,7 +282,7 @@ __device__ __forceinline__ void level_bit2(float (&lo)[6], const float (&hi)[6])
             "v_add_f32_dpp %5, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
             "v_add_f32_dpp %5, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
             "s_nop 1"
-        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5])
+        : "+&v"(lo[0]), "+&v"(lo[1]), "+&v"(lo[2]), "+&v"(lo[3]), "+&v"(lo[4]), "+&v"(lo[5])
         : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]));
 }
 __device__ __forceinline__ void level_bit2(float (&lo)[4], const float (&hi)[4])
@@ -294,7 +297,7 @@ __device__ __forceinline__ void level_bit2(float (&lo)[4], const float (&hi)[4])
             "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
             "v_add_f32_dpp %3, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
             "s_nop 1"
-        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3])
+        : "+&v"(lo[0]), "+&v"(lo[1]), "+&v"(lo[2]), "+&v"(lo[3])
         : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
 }
 

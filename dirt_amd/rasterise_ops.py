@@ -407,24 +407,65 @@ def _rasterise_grad_multichannel(vertices, faces, pixels, d_loss_by_pixels, sing
     return {'grad_vertices': gv, 'grad_vertex_colors': gvc, 'grad_background': gb}
 
 
-_checked_shaders = collections.OrderedDict()   # shader functions (by code AND by what they close over) whose graph was walked
+_checked_shaders = collections.OrderedDict()   # code object (or id of a callable without one) -> closures of it whose graph was walked
 _CHECKED_SHADERS_MAX = 256
+_WALKS_PER_CODE = 4   # distinct closures of one code object that get the graph walk; a lambda re-created every step over
+                      # fresh tensors (the common training-loop pattern) then stops paying for it after four steps
 
 
-def _shader_key(shader_fn):
-    """What identifies a shader for the one-time graph walk: its code object together with the identities of the objects
-    it closes over / is bound to -- two closures of one factory share a code object but not their parameters, and a
-    lambda re-created per call with the same captured tensors need not be walked again."""
+def _closure_identity(shader_fn):
+    """(code object, objects the function closes over / is bound to): what identifies a shader for the one-time graph walk.
+    Two closures of one factory share a code object but not their parameters."""
     fn = shader_fn if hasattr(shader_fn, '__code__') else getattr(shader_fn, '__call__', shader_fn)
     code = getattr(fn, '__code__', None)
-    cells = ()
+    held = []
     for c in (getattr(fn, '__closure__', None) or ()):
         try:
-            cells += (id(c.cell_contents),)
+            held.append(c.cell_contents)
         except ValueError:   # an empty cell
-            cells += (0,)
-    bound = id(getattr(fn, '__self__', None)) if getattr(fn, '__self__', None) is not None else 0
-    return (code if code is not None else id(shader_fn), cells, bound)
+            held.append(None)
+    held.append(getattr(fn, '__self__', None))
+    return (code if code is not None else id(shader_fn)), held
+
+
+def _ref(obj):
+    """A weak reference where the object allows one (tensors, modules, functions); else the object itself (ints, tuples:
+    small immutables whose identity cannot be recycled to mean something else while the entry compares them by value)."""
+    import weakref
+    try:
+        return weakref.ref(obj)
+    except TypeError:
+        return obj
+
+
+def _same(entry, held):
+    import weakref
+    if len(entry) != len(held):
+        return False
+    for r, o in zip(entry, held):
+        if isinstance(r, weakref.ref):
+            if r() is None or r() is not o:     # a dead referent never matches: ids of freed objects get reused, references do not
+                return False
+        elif r is not o and r != o:
+            return False
+    return True
+
+
+def _shader_needs_walk(shader_fn):
+    """True the first time this (code, closure) is seen -- and only for the first _WALKS_PER_CODE closures of a code object."""
+    code, held = _closure_identity(shader_fn)
+    entries = _checked_shaders.get(code)
+    if entries is None:
+        entries = _checked_shaders[code] = []
+    _checked_shaders.move_to_end(code)
+    while len(_checked_shaders) > _CHECKED_SHADERS_MAX:   # bounded: a job that builds shaders as it goes does not grow it
+        _checked_shaders.popitem(last=False)
+    if any(_same(e, held) for e in entries):
+        return False
+    if len(entries) >= _WALKS_PER_CODE:
+        return False
+    entries.append([_ref(o) for o in held])
+    return True
 
 
 def _unlisted_leaves(output, listed, limit=2000):
@@ -472,12 +513,7 @@ class _RasteriseDeferred(torch.autograd.Function):
                         for t in shader_additional_inputs]
             pixels = shader_fn(gbuffer_in, *extra_in)
         # (the graph walk is a debugging aid with a host-side cost: done on the first call of each shader function only)
-        key = _shader_key(shader_fn)
-        stray = [] if key in _checked_shaders else _unlisted_leaves(pixels, [gbuffer_in] + list(extra_in) + list(shader_params))
-        _checked_shaders[key] = True
-        _checked_shaders.move_to_end(key)
-        while len(_checked_shaders) > _CHECKED_SHADERS_MAX:   # bounded: a job that builds shaders as it goes does not grow it
-            _checked_shaders.popitem(last=False)
+        stray = _unlisted_leaves(pixels, [gbuffer_in] + list(extra_in) + list(shader_params)) if _shader_needs_walk(shader_fn) else []
         if stray:
             import warnings
             warnings.warn('rasterise_deferred: shader_fn uses %d tensor(s) that require grad but are neither '

@@ -19,6 +19,21 @@ import ctypes
 import math
 import numpy as np
 
+
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def no_bytecode():
+    """Importing a module from /root/reference must not write __pycache__ there (the reference tree is read-only by policy)."""
+    import sys
+    old = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True
+    try:
+        yield
+    finally:
+        sys.dont_write_bytecode = old
+
 from . import make_ref
 from . import oracle as _oracle
 
@@ -238,7 +253,7 @@ def run_reference_script(path, entry='main'):
         spec = importlib.util.spec_from_file_location('dirt_reference_script', path)
         module = importlib.util.module_from_spec(spec)
         out = io.StringIO()
-        with contextlib.redirect_stdout(out):
+        with contextlib.redirect_stdout(out), no_bytecode():
             spec.loader.exec_module(module)
             getattr(module, entry)()
         return out.getvalue()
@@ -274,7 +289,8 @@ def python_layer():
         tf_shim._op_library = OpLibrary
         spec = importlib.util.spec_from_file_location('dirt_reference_rasterise_ops', path)
         module = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(module)
+        with no_bytecode():
+            spec.loader.exec_module(module)
         assert module._rasterise_module is OpLibrary
         module.tf_shim = tf_shim
         _python_layer = module

@@ -1,6 +1,6 @@
 """Randomised parity sweep on an MI355X box: random frame sizes, channel counts, meshes (split / shared / hostile),
 kernel tile shapes and flags; every case compares the HIP path with the CPU oracle (forward
-and visibility bit for bit, gradients per element within 1e-4 of the L1 mass of their terms, non-finite values in the same
+and visibility bit for bit, gradients per element within 5e-6 (parity.TIGHT_TOL; the specification says 1e-4) of the L1 mass of their terms, non-finite values in the same
 places: tests/parity.py).  A fixed-seed slice of it runs under pytest (tests/test_gpu_configs.py); as a script it is open-ended (a time budget);
 usage: python tests/fuzz_parity.py [seconds] [seed] [hostile]   (`hostile`: mostly hostile geometry, larger frames)"""
 import os
@@ -53,7 +53,7 @@ def run(budget=None, max_cases=None, seed=0, hard=False, max_dim=None, failures=
         gb, gv, gvc, _ = ops._op_rasterise_grad(t(b['vertices']), t(b['faces']), t(want), t(b['grad_pixels']), H, W, C, flags=flags, state=state)
         assert np.array_equal(gb.cpu().numpy(), ow['grad_background']), ('grad_background', tag)
         try:
-            parity.grads_close(gv, gvc, ow, str(tag))
+            parity.grads_close(gv, gvc, ow, str(tag), tol=parity.TIGHT_TOL)
         except AssertionError as e:
             if failures is None:
                 raise

@@ -34,7 +34,11 @@ def load_reference_helpers():
         for name in ('matrices', 'lighting', 'projection'):
             spec = importlib.util.spec_from_file_location('dirt_reference_' + name, os.path.join(REF, name + '.py'))
             m = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(m)
+            old, sys.dont_write_bytecode = sys.dont_write_bytecode, True   # no __pycache__ under /root/reference (read-only by policy)
+            try:
+                spec.loader.exec_module(m)
+            finally:
+                sys.dont_write_bytecode = old
             mods.append(m)
         return tuple(mods)
     finally:

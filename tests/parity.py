@@ -22,6 +22,7 @@ Non-finite values (hostile geometry: clip_w underflow) must be non-finite on bot
 import numpy as np
 
 GRAD_TOL = 1e-4
+TIGHT_TOL = 5e-6  # 10 x the worst measured error / mass (5.4e-7, hostile geometry: profiles/r04_tolerance_probe.txt); what the GPU tests assert
 COND_ULPS = 2.0 ** -20   # 16 float32 ulps of the cancellation scale
 KEYS = {'grad_vertices': 'mass_vertices', 'grad_vertex_colors': 'mass_vertex_colors'}
 

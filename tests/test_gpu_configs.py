@@ -14,7 +14,7 @@ from tests import parity
 
 pytestmark = pytest.mark.gpu
 GRAD_TOL = 1e-4  # BASELINE.json north_star
-TIGHT_TOL = 5e-6  # 10 x the worst measured error / mass (5.4e-7, hostile geometry: profiles/r04_tolerance_probe.txt)
+TIGHT_TOL = parity.TIGHT_TOL
 
 
 def _t(a, dev):

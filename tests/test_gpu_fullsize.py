@@ -343,3 +343,85 @@ def test_k5_through_rasterise_deferred_at_full_size(gpu, oracle):
     parity.grad_close(attrs.grad, want_a, 'grad_vertex_colors', 'K5 deferred: attributes (from the G-buffer)', 0)
     assert np.array_equal(bg.grad.cpu().numpy(), want_a['grad_background'][0]), 'K5 deferred: background attributes'
     assert torch.allclose(light.grad, l2.grad, rtol=1e-4, atol=1e-3 * float(l2.grad.abs().max()))
+
+
+def test_graphed_step_equals_the_eager_autograd_path(gpu, oracle):
+    """dirt_amd.GraphedStep: rasterise_batch -> loss -> gradients captured once as a HIP graph (the remedy for eager
+    autograd's host cost; the reference registers its gradient into a TensorFlow graph that session.run replays,
+    dirt/rasterise_ops.py:111-129).  Replays must give the eager path's pixels bit for bit and gradients within the tight
+    per-element tolerance of the oracle; inputs updated IN PLACE between replays must be seen; the vjp form
+    (grad_pixels) must equal backward(grad_pixels)."""
+    import dirt_amd
+    TIGHT_TOL = parity.TIGHT_TOL
+    F, H, W, C = 600, 160, 192, 4
+    s = scenes.rand_scene(F, H, W, C, 31, 0.02, 0.2)
+    bg, v, vc, f, g = (torch.from_numpy(s[k][None].copy()).to(gpu) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels'))
+    # vjp form
+    step = dirt_amd.GraphedStep(bg, v, vc, f, grad_pixels=g)
+    for _ in range(3):
+        px, (gb, gv, gvc) = step()
+    torch.cuda.synchronize()
+    want = oracle.forward(s['background'][None], s['vertices'][None], s['vertex_colors'][None], s['faces'][None])
+    assert np.array_equal(px.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    ow = oracle.backward(s['vertices'][None], s['faces'][None], want, s['grad_pixels'][None], want_mass=True)
+    assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
+    parity.grads_close(gv, gvc, ow, 'graphed vjp', tol=TIGHT_TOL)
+    assert gv.is_contiguous() and gvc.is_contiguous() and tuple(gv.shape) == (1, v.shape[1], 4) and tuple(gvc.shape) == (1, v.shape[1], C)
+    # inputs updated in place are what the next replay renders
+    with torch.no_grad():
+        v[..., 0] += 0.03 * v[..., 3]
+        g.mul_(0.5)
+    px, (gb, gv, gvc) = step()
+    torch.cuda.synchronize()
+    v2 = v.cpu().numpy()
+    want2 = oracle.forward(s['background'][None], v2, s['vertex_colors'][None], s['faces'][None])
+    assert np.array_equal(px.cpu().numpy().view(np.uint32), want2.view(np.uint32))
+    ow2 = oracle.backward(v2, s['faces'][None], want2, g.cpu().numpy(), want_mass=True)
+    parity.grads_close(gv, gvc, ow2, 'graphed vjp after an in-place update', tol=TIGHT_TOL)
+    # loss form against eager autograd on the same tensors
+    target = torch.rand_like(bg)
+    loss_fn = lambda p: ((p - target) ** 2).mean()
+    step2 = dirt_amd.GraphedStep(bg, v, vc, f, loss_fn=loss_fn)
+    loss, (gb, gv, gvc) = step2()
+    leaves = [t.detach().clone().requires_grad_(True) for t in (bg, v, vc)]
+    eager_loss = loss_fn(dirt_amd.rasterise_batch(leaves[0], leaves[1], leaves[2], f))
+    eager_loss.backward()
+    torch.cuda.synchronize()
+    assert float((loss - eager_loss).abs()) <= 1e-6 * max(1.0, float(eager_loss.abs()))
+    assert torch.equal(gb, leaves[0].grad)
+    gp = (2.0 / target.numel()) * (torch.from_numpy(want2).to(gpu) - target)
+    ow3 = oracle.backward(v2, s['faces'][None], want2, gp.cpu().numpy(), want_mass=True)
+    parity.grads_close(gv, gvc, ow3, 'graphed loss', tol=TIGHT_TOL)
+    parity.grads_close(leaves[1].grad, leaves[2].grad, ow3, 'eager loss', tol=TIGHT_TOL)
+
+
+def test_second_backward_over_one_forward_returns_its_own_gradients(gpu, oracle):
+    """The RasteriseGrad op is pure (csrc/rasterise_grad_egl.cu:244-250 clears its outputs on every call).  Here a keep-state
+    forward pre-clears what ONE backward call adds into; the library remembers (host side, per workspace) whether that is
+    still so and clears otherwise -- at the C-ABI level, not only in the autograd wrapper: a second call with
+    DIRT_FLAG_DENSE_FROM_STATE, with the state's own accumulators as outputs, or with DIRT_FLAG_OUTPUTS_CLEARED must not
+    return the sum of two passes."""
+    F, H, W, C = 300, 96, 128, 4
+    s = scenes.rand_scene(F, H, W, C, 17, 0.03, 0.25)
+    b = {k: s[k][None] for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
+    d = {k: torch.from_numpy(np.ascontiguousarray(b[k])).to(gpu) for k in b}
+    want = oracle.forward(b['background'], b['vertices'], b['vertex_colors'], b['faces'])
+    ow = oracle.backward(b['vertices'], b['faces'], want, b['grad_pixels'], want_mass=True)
+    for mode in ('dense', True):
+        for dense_grads in (False, True):
+            px, state = ops._op_rasterise(d['background'], d['vertices'], d['vertex_colors'], d['faces'], H, W, C, keep_state=True, dense_grads=dense_grads)
+            for call in range(3):
+                _, gv, gvc, _ = ops._op_rasterise_grad(d['vertices'], d['faces'], px, d['grad_pixels'], H, W, C, state=state, state_outputs=mode)
+                parity.grads_close(gv.clone(), gvc.clone(), ow, 'call %d, state_outputs=%r, dense_grads=%r' % (call, mode, dense_grads))
+    # the raw C ABI: OUTPUTS_CLEARED with tensors the forward never saw must clear them, not trust the flag
+    from dirt_amd import _lib
+    px, state = ops._op_rasterise(d['background'], d['vertices'], d['vertex_colors'], d['faces'], H, W, C, keep_state=True, dense_grads=True)
+    gv = torch.full_like(d['vertices'], 7.0)
+    gvc = torch.full((1, d['vertices'].shape[1], C), 7.0, device=gpu)
+    gb = torch.empty_like(px)
+    lib = _lib.load()
+    _lib.check(lib.dirt_rasterise_backward(d['vertices'].data_ptr(), d['faces'].data_ptr(), px.data_ptr(), d['grad_pixels'].data_ptr(),
+                                           gb.data_ptr(), gv.data_ptr(), gvc.data_ptr(), None, 1, d['vertices'].shape[1], F, H, W, C,
+                                           state.data_ptr(), state.numel(), _lib.FLAG_REUSE_STATE | _lib.FLAG_OUTPUTS_CLEARED,
+                                           torch.cuda.current_stream().cuda_stream))
+    parity.grads_close(gv, gvc, ow, 'OUTPUTS_CLEARED on foreign tensors')

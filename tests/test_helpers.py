@@ -241,11 +241,15 @@ def test_unlisted_shader_parameters_are_detected():
     assert _unlisted_leaves(torch.ones(3), [g]) == []          # no graph at all
 
 
-def test_shader_key_tells_closures_of_one_factory_apart():
+def test_shader_walk_tells_closures_of_one_factory_apart():
     """The one-time graph walk of rasterise_deferred is keyed on the shader's code AND on what it closes over: two
     closures of one factory (same code object, different captured parameters) must each be walked; the same closure
-    again must not."""
-    from dirt_amd.rasterise_ops import _shader_key
+    again must not.  The captured objects are held by weak reference -- the id of a freed tensor can be reused by another
+    object, a dead reference cannot match -- and a lambda re-created per step over fresh tensors is walked only the
+    first few times (the walk is a debugging aid with a host-side cost)."""
+    import gc
+    from dirt_amd import rasterise_ops as ops
+    ops._checked_shaders.clear()
 
     def factory(w):
         return lambda g: g * w
@@ -253,8 +257,8 @@ def test_shader_key_tells_closures_of_one_factory_apart():
     wa, wb = torch.ones(3, requires_grad=True), torch.ones(3, requires_grad=True)
     fa, fb = factory(wa), factory(wb)
     assert fa.__code__ is fb.__code__
-    assert _shader_key(fa) != _shader_key(fb)
-    assert _shader_key(fa) == _shader_key(fa) == _shader_key(factory(wa))
+    assert ops._shader_needs_walk(fa) and ops._shader_needs_walk(fb)
+    assert not ops._shader_needs_walk(fa) and not ops._shader_needs_walk(factory(wa)) and not ops._shader_needs_walk(fb)
 
     class Shader:
         def __init__(self, w):
@@ -264,4 +268,18 @@ def test_shader_key_tells_closures_of_one_factory_apart():
             return g * self.w
 
     sa, sb = Shader(wa), Shader(wb)
-    assert _shader_key(sa) != _shader_key(sb) and _shader_key(sa) == _shader_key(sa)
+    assert ops._shader_needs_walk(sa) and ops._shader_needs_walk(sb) and not ops._shader_needs_walk(sa)
+
+    # a captured tensor that died: whatever object is created next (possibly at the same address) is a NEW closure
+    ops._checked_shaders.clear()
+    w = torch.ones(3, requires_grad=True)
+    assert ops._shader_needs_walk(factory(w))
+    del w
+    gc.collect()
+    w2 = torch.ones(3, requires_grad=True)
+    assert ops._shader_needs_walk(factory(w2))
+    # the training-loop pattern: a fresh lambda over fresh tensors every step is walked at most _WALKS_PER_CODE times
+    ops._checked_shaders.clear()
+    keep = [torch.ones(2, requires_grad=True) for _ in range(10)]
+    assert sum(ops._shader_needs_walk(factory(t)) for t in keep) == ops._WALKS_PER_CODE
+    ops._checked_shaders.clear()
