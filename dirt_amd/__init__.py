@@ -4,4 +4,4 @@ from .rasterise_ops import rasterise, rasterise_batch, rasterise_deferred, raste
 from . import rasterise_ops  # noqa: F401
 from . import matrices, lighting, projection  # noqa: F401  (dirt.matrices, dirt.lighting, dirt.projection)
 from . import texture  # noqa: F401  (the texture helpers of samples/textured.py)
-from .graphed import GraphedStep  # noqa: F401  (a training step captured once as a HIP graph: the remedy for eager autograd's host cost)
+from .graphed import GraphedStep, backward  # noqa: F401  (a training step captured once as a HIP graph: the remedy for eager autograd's host cost)

@@ -42,7 +42,9 @@ extern "C" void dirt_debug_set_trace_grad_px2(void* p)
 #endif
 
 #ifndef DIRT_PX2_WAVES
-#define DIRT_PX2_WAVES 5   // waves per SIMD the register allocation aims at (<= 96 VGPRs)
+#define DIRT_PX2_WAVES(C_, DEBUG_) ((C_) == 4 ? 5 : ((DEBUG_) ? 7 : 8))   // waves per SIMD the register allocation aims at: 88 VGPRs for 4 channels (two channel
+                                                 // groups), 60-64 for 1 and 3 (all 2048 workgroups of a 1024 x 1024 frame resident; the debug_thingy
+                                                 // variants would spill at that: scratch memory costs far more than a wave)
 #endif
 
 namespace {
@@ -52,7 +54,8 @@ constexpr int XTHREADS = 256;           // 4 waves: wave w owns the 16 x 8 regio
 constexpr int XR = YT + 2;              // staged rows: y0 - 1 .. y0 + 16
 constexpr int XPS = 40;                 // plane row stride (floats): index (x - x0) + 1 for x0 - 1 .. x0 + 34; 40: the 8-byte tap reads of
                                         // the 32 lanes of an 8 x 8 block (rows 40 y + 2 q) fall on 64 distinct banks
-constexpr int XVS = 40;                 // state tile row stride (float2): index (x - x0) + 2 for x0 - 1 .. x0 + 32, pairs 16-byte aligned
+constexpr int XVS = 36;                 // state tile row stride (float2): index (x - x0) + 2 for x0 - 1 .. x0 + 32, pairs 16-byte aligned
+                                        // (36, not the conflict-free 40: the 3-channel kernel then fits eight workgroups per compute unit)
 constexpr int XIS = 20;                 // inbox row stride (float2 cells): cell (ty + 1) * 20 + tx + 2 for ty in -1..8, tx in -1..16
 constexpr int XICELLS = 10 * XIS;       // ... of a wave's 16 x 8 region and the one-pixel ring around it
 constexpr int XRING = 2 * 18 + 2 * 8;   // ring cells: one per lane (52 of 64)
@@ -108,7 +111,7 @@ __device__ __forceinline__ uint32_t alias_wrap_fixup_rolled(const float* __restr
 // grad_kernel_px2<CSPEC, DEBUG>: the image has CSPEC = 1, 3 or 4 channels (4 = a 3-channel group and a single; 16-byte
 // aligned pixel tensors).  DEBUG: also write the reference's diagnostic output debug_thingy.
 template <int CSPEC, bool DEBUG>
-__global__ __launch_bounds__(XTHREADS, DIRT_PX2_WAVES) void grad_kernel_px2(GradParams p)
+__global__ __launch_bounds__(XTHREADS, DIRT_PX2_WAVES(CSPEC, DEBUG)) void grad_kernel_px2(GradParams p)
 {
     static_assert(CSPEC == 1 || CSPEC == 3 || CSPEC == 4, "channel counts with a two-pixels-per-lane kernel");
     constexpr int NCH = CSPEC, C = CSPEC;

@@ -23,7 +23,7 @@ import torch
 
 from . import rasterise_ops as ops
 
-__all__ = ['GraphedStep']
+__all__ = ['GraphedStep', 'backward']
 
 
 class GraphedStep:
@@ -87,3 +87,17 @@ class GraphedStep:
         return (self.loss if self.loss is not None else self.pixels), self.grads
 
     replay = __call__
+
+
+def backward(tensors, grad_tensors=None, **kwargs):
+    """`torch.autograd.backward(tensors, grad_tensors, ...)` with torch's backward engine kept on the CALLING thread for the
+    duration of the call (a scoped `torch.autograd.set_multithreading_enabled(False)`, restored on return -- no process-wide
+    switch).  By default the engine hands every GPU node to a per-device worker thread and waits for it: two thread wake-ups
+    per backward(), ~100 us of a 160 us eager step at 1024 x 1024 (bench.py: `ms_per_step_autograd` against
+    `..._engine_on_calling_thread`).  For loops whose shapes change from step to step (where GraphedStep does not apply):
+
+        loss = loss_fn(dirt_amd.rasterise_batch(background, vertices, vertex_colors, faces))
+        dirt_amd.backward(loss)          # instead of loss.backward()
+    """
+    with torch.autograd.set_multithreading_enabled(False):
+        torch.autograd.backward(tensors, grad_tensors, **kwargs)
