@@ -31,6 +31,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# RCCL / cross-process sharing of device memory needs dmabuf IPC on this pool's host driver (without it
+# hipIpcGetMemHandle fails with "invalid argument"); exported by the environment already -- kept here for any other launcher
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -68,6 +68,26 @@ def test_baseline_config_matches_oracle(gpu, oracle, config):
     parity.grads_close(gv, gvc, ow, config + ' tight', tol=TIGHT_TOL)
 
 
+@pytest.mark.parametrize('config,flags', [('K3', 0x8000), ('K3-768', 0), ('K3-3ch', 0), ('K3-1ch', 0x8000), ('K3-2048', 0x8000)])
+def test_two_pixel_gradient_kernel_at_full_size(gpu, oracle, config, flags):
+    """grad_kernel_px2 (two pixels per lane, 32 x 16 tiles; round 5) on the benchmarked meshes at full size: pinned with
+    DIRT_FLAG_GRAD_PX2 where the library would pick the 4-pixel kernel, unpinned where it is the library's own choice
+    (K3-768, K3-3ch) -- dense outputs cleared by the forward launch, as the autograd path uses them: grad_background bit for
+    bit, every vertex gradient within 5e-6 of its terms' mass."""
+    s = scenes.config_scene(config)
+    b = {k: s[k][None] for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
+    H, W, C = b['background'].shape[1:]
+    want = oracle.forward(b['background'], b['vertices'], b['vertex_colors'], b['faces'])
+    ow = oracle.backward(b['vertices'], b['faces'], want, b['grad_pixels'], want_mass=True)
+    d = {k: _t(b[k], gpu) for k in b}
+    px, state = ops._op_rasterise(d['background'], d['vertices'], d['vertex_colors'], d['faces'], H, W, C, keep_state=True, dense_grads=True)
+    assert np.array_equal(px.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    gb, gv, gvc, _ = ops._op_rasterise_grad(d['vertices'], d['faces'], px, d['grad_pixels'], H, W, C, flags=flags, state=state, state_outputs='dense')
+    assert gv.is_contiguous() and gvc.is_contiguous()
+    assert np.array_equal(gb.cpu().numpy(), ow['grad_background'])
+    parity.grads_close(gv, gvc, ow, config + ' px2', tol=TIGHT_TOL)
+
+
 def test_cube_k2_with_gradients(gpu, oracle):
     """K2: the Gouraud cube of samples/simple.py at 256 x 256 x 3, forward and gradients."""
     s = scenes.cube_scene(256, 256)
