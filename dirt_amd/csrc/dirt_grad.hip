@@ -480,10 +480,10 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
         const float4 i01 = *reinterpret_cast<const float4*>(inbox + my_cell), i23 = *reinterpret_cast<const float4*>(inbox + my_cell + 2);
         fpos_xy[0] = fxy[0] + float2v{i01.x, i01.y}; fpos_xy[1] = fxy[1] + float2v{i01.z, i01.w};
         fpos_xy[2] = fxy[2] + float2v{i23.x, i23.y}; fpos_xy[3] = fxy[3] + float2v{i23.z, i23.w};
-        const float ndc_y_own = ((float)(H - 1 - y) + 0.5f) * p.two_over_h - 1.f;
+        const float ndc_y_own = ndc_of(H - 1 - y, H, p.inv_h);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float ndc_x = ((float)(xs + j) + 0.5f) * p.two_over_w - 1.f;
+            const float ndc_x = ndc_of(xs + j, W, p.inv_w);
             fpos_w[j] = -(fpos_xy[j].x * ndc_x + fpos_xy[j].y * ndc_y_own);
         }
 #pragma unroll
@@ -501,8 +501,8 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
                     lkey[e] = __float_as_int(s_vw[8 * wave + ty + 1][tx + 2].y);
                     const float2 nb = ld_off<float2>(state_b, (uint32_t)((py - row0) * W + px) * 8u);
                     decode_bary(nb, lb[e]);
-                    const float ndc_x = ((float)px + 0.5f) * p.two_over_w - 1.f;
-                    const float ndc_y = ((float)(H - 1 - py) + 0.5f) * p.two_over_h - 1.f;
+                    const float ndc_x = ndc_of(px, W, p.inv_w);
+                    const float ndc_y = ndc_of(H - 1 - py, H, p.inv_h);
                     lf[e][0] = v.x; lf[e][1] = v.y; lf[e][2] = -(v.x * ndc_x + v.y * ndc_y);
                     if (!__builtin_isfinite((v.x + v.y) + ((lb[e][0] + lb[e][1]) + lb[e][2]))) {   // (see the face loop: non-finite factors)
                         const uint32_t fo = (uint32_t)lkey[e] * 12u;
@@ -928,7 +928,7 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     p.tiles_x = (p.W + GT - 1) / GT;
     p.tiles_y = (p.H + GT - 1) / GT;
     p.tiles_x_magic = tile_magic(p.tiles_x);
-    p.two_over_w = 2.f / (float)p.W; p.two_over_h = 2.f / (float)p.H;   // (IEEE divisions, as the kernel's own would be)
+    p.inv_w = 1.f / (float)p.W; p.inv_h = 1.f / (float)p.H;   // (IEEE divisions, as the kernel's own would be)
     p.pixels_aligned16 = ((reinterpret_cast<uintptr_t>(p.pixels) | reinterpret_cast<uintptr_t>(p.grad_pixels) |
                            reinterpret_cast<uintptr_t>(p.grad_background)) & 15u) == 0 ? 1 : 0;
 #ifdef DIRT_TRACE

@@ -97,6 +97,16 @@ __device__ __forceinline__ float2v pk_mul_scalar(float s, float2v b)
 }
 #pragma clang diagnostic pop
 
+// NDC coordinate of the centre of pixel i of n: (2 i + 1 - n) / n.  The numerator is an exact small integer, so the result carries
+// two roundings RELATIVE to its own size -- where ((i + 0.5) * (2 / n)) - 1 has an absolute error of an ulp of 1 whatever the
+// value, i.e. no correct digit at the centre of the frame: there the reference's clip_x = sum_k b_k * vertex_k.x (:210-217), which
+// this stands for, is small and accurate, and the position gradient's w term differed by up to 27 ulps of that sum's scale
+// (round 5 fuzz sweep: two elements in 1 727 cases beyond the tolerance's cancellation term; none since).
+__device__ __forceinline__ float ndc_of(int i, int n, float inv_n)
+{
+    return (float)(2 * i + 1 - n) * inv_n;
+}
+
 struct Float3 { float x, y, z; };   // three channels of a pixel: one 12-byte load / store (4-byte aligned)
 
 // Loads / stores at a 32-bit byte offset from a wave-uniform base: the address stays "scalar base + vector offset"

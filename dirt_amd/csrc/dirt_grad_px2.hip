@@ -447,10 +447,10 @@ __global__ __launch_bounds__(XTHREADS, DIRT_PX2_WAVES(CSPEC, DEBUG)) void grad_k
     {
         const float4 i01 = *reinterpret_cast<const float4*>(inbox + my_cell);
         fpos_xy[0] = fxy[0] + float2v{i01.x, i01.y}; fpos_xy[1] = fxy[1] + float2v{i01.z, i01.w};
-        const float ndc_y_own = ((float)(H - 1 - y) + 0.5f) * p.two_over_h - 1.f;
+        const float ndc_y_own = ndc_of(H - 1 - y, H, p.inv_h);
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
-            const float ndc_x = ((float)(xs + j) + 0.5f) * p.two_over_w - 1.f;
+            const float ndc_x = ndc_of(xs + j, W, p.inv_w);
             fpos_w[j] = -(fpos_xy[j].x * ndc_x + fpos_xy[j].y * ndc_y_own);
         }
         const int r = lane;
@@ -464,8 +464,8 @@ __global__ __launch_bounds__(XTHREADS, DIRT_PX2_WAVES(CSPEC, DEBUG)) void grad_k
                 lkey = __float_as_int(s_vw[wy0 + ty + 1][wx0 + tx + 2].y);
                 const float2 nb = ld_off<float2>(state_b, (uint32_t)((py - row0) * W + px) * 8u);
                 decode_bary(nb, lb);
-                const float ndc_x = ((float)px + 0.5f) * p.two_over_w - 1.f;
-                const float ndc_y = ((float)(H - 1 - py) + 0.5f) * p.two_over_h - 1.f;
+                const float ndc_x = ndc_of(px, W, p.inv_w);
+                const float ndc_y = ndc_of(H - 1 - py, H, p.inv_h);
                 lf[0] = v.x; lf[1] = v.y; lf[2] = -(v.x * ndc_x + v.y * ndc_y);
                 if (!__builtin_isfinite((v.x + v.y) + ((lb[0] + lb[1]) + lb[2]))) {   // (see the face loop: non-finite factors)
                     const uint32_t fo = (uint32_t)lkey * 12u;

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
     // ---- totals per target pixel: own + what the neighbours sent; the ring cells (targets outside this wave's region) ----
     const float2 in_own = inbox[my_cell];
     const float px_x = fx + in_own.x, px_y = fy + in_own.y;
-    const float ndc_x = ((float)x + 0.5f) * p.two_over_w - 1.f, ndc_y = ((float)(H - 1 - y) + 0.5f) * p.two_over_h - 1.f;
+    const float ndc_x = ndc_of(x, W, p.inv_w), ndc_y = ndc_of(H - 1 - y, H, p.inv_h);
     const float px_w = -(px_x * ndc_x + px_y * ndc_y);
     int lkey = -1;
     Int3 lvid = {0, 0, 0};
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void grad_kernel_px1(GradParams p)
             lkey = __float_as_int(s_vw[tly + 1][tlx + 1].y);
             lvid = *reinterpret_cast<const Int3*>(faces + (size_t)lkey * 3);
             decode_bary(state_b[(size_t)py * W + pxx], lb);
-            const float nx = ((float)pxx + 0.5f) * p.two_over_w - 1.f, ny = ((float)(H - 1 - py) + 0.5f) * p.two_over_h - 1.f;
+            const float nx = ndc_of(pxx, W, p.inv_w), ny = ndc_of(H - 1 - py, H, p.inv_h);
             lf[0] = v.x; lf[1] = v.y; lf[2] = -(v.x * nx + v.y * ny);
         }
     }

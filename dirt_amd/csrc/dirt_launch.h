@@ -86,7 +86,7 @@ struct GradParams {
     int last_second;           // the {3,3} shape: what the LAST pass of the launch has as its second group: 0 a triple, 1 a single, 2 nothing
     int gbk_split;             // strided launches: > 0: the launch's passes write grad_background of ALL channels, a share of the tile's
                                // rows each (whole lines); 0: another launch of the call does; < 0: every pass stores its own channels
-    float two_over_w, two_over_h;  // 2 / W, 2 / H (pixel -> NDC), filled by launch_grad
+    float inv_w, inv_h;        // 1 / W, 1 / H (pixel -> NDC: ndc_of), filled by launch_grad
 };
 
 BinGrid make_bin_grid(int H, int W);
