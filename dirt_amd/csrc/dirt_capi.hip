@@ -244,6 +244,7 @@ dirt::GeomParams geom_params(const Carved& c, const float* vertices, const int32
     g.vertices = vertices; g.faces = faces; g.recs = c.recs; g.boxes = c.boxes; g.cells = c.cells;
     g.entries = c.entries;
     dirt::chunking(F, g.nchunk, g.chunk_faces);
+    g.masked = dirt::directory_is_masked(g.chunk_faces) ? 1 : 0;
     g.B = B; g.V = V; g.F = F; g.H = H; g.W = W;
     g.grid = dirt::make_bin_grid(H, W);
     return g;
@@ -253,7 +254,7 @@ dirt::RasterParams raster_params(const Carved& c, const dirt::GeomParams& g, int
 {
     dirt::RasterParams p;
     p.flags = flags;
-    p.recs = c.recs; p.cells = c.cells; p.entries = c.entries; p.nchunk = g.nchunk; p.chunk_faces = g.chunk_faces;
+    p.recs = c.recs; p.cells = c.cells; p.entries = c.entries; p.nchunk = g.nchunk; p.chunk_faces = g.chunk_faces; p.masked = g.masked;
     p.background = nullptr; p.vertex_colors = nullptr; p.pixels = nullptr; p.vis = nullptr; p.state_a = nullptr; p.state_b = nullptr;
     p.V = g.V; p.F = g.F; p.H = g.H; p.W = g.W; p.C = C;
     p.grid = g.grid; p.tiles_x = 0; p.tiles_y = 0;

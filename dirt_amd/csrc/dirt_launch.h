@@ -38,6 +38,7 @@ struct GeomParams {
     BinEntry* entries;      // [B][nchunk][5 * chunk_faces] per-chunk entry segments, sorted by bin
     int B, V, F, H, W;
     int nchunk, chunk_faces;  // faces are processed in nchunk contiguous chunks per scene
+    int masked;               // chunk_faces == 64: a directory cell is the 64-bit mask of the chunk's faces that touch the bin (filled by launch_geometry's callers: directory_is_masked)
     BinGrid grid;
 };
 
@@ -46,6 +47,7 @@ struct RasterParams {
     const BinCell* cells;        // [B][nchunk][MAX_BINS + 1] chunk x bin directory
     const BinEntry* entries;     // [B][nchunk][5 * chunk_faces] per-chunk entry segments, sorted by bin
     int nchunk, chunk_faces;
+    int masked;                  // the directory holds face masks, entries have fixed slots (chunks of 64 faces: setup_kernel_masked)
     const float* background;     // [B,H,W,C]
     const float* vertex_colors;  // [B,V,C]
     float* pixels;               // [B,H,W,C]
@@ -91,6 +93,11 @@ struct GradParams {
 
 BinGrid make_bin_grid(int H, int W);
 void chunking(int F, int& nchunk, int& chunk_faces);
+#ifdef DIRT_NO_MASKED_DIR   // (A/B builds: rounds 1-4's start / count directory for every mesh)
+inline bool directory_is_masked(int) { return false; }
+#else
+inline bool directory_is_masked(int chunk_faces) { return chunk_faces == 64; }   // one face per lane of a one-wave set-up workgroup
+#endif
 hipError_t launch_zero(void* b, size_t b_bytes, void* c, size_t c_bytes, hipStream_t stream);
 hipError_t launch_unpack(const float* acc_gv, const float* acc_gvc, int acc_stride, float* gv, float* gvc, int C, size_t rows, hipStream_t stream);
 hipError_t launch_geometry(const GeomParams& g, hipStream_t stream);

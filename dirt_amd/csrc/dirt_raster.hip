@@ -194,6 +194,77 @@ __global__ __launch_bounds__(STHREADS * NW) void setup_kernel(GeomParams g)
 #endif
 }
 
+// setup_kernel_masked (round 5): chunks of exactly 64 faces -- meshes of up to 16 384 faces --, one face per lane of a single
+// wave.  The chunk's row of the directory is, per (pseudo-)bin, the 64-bit MASK of the chunk's faces that touch it, and a
+// face's entry {box, face} has a FIXED slot (lane l of chunk c: entry l of the chunk's segment), written once, coalesced.
+// Rounds 1-4 (setup_kernel, still used for larger chunks) stored a start / count pair into a bin-sorted segment, which took
+// a prefix over the 257 bins and a second pass in which every face claimed its slots with LDS cursors: 2 400 of the wave's
+// 8 200 clocks (tools/trace_setup.py).  A raster tile walks the set bits of its bin's masks.
+__global__ __launch_bounds__(STHREADS) void setup_kernel_masked(GeomParams g)
+{
+    __shared__ unsigned long long s_mask[MAX_BINS + 1];    // [MAX_BINS] = big faces
+    const int ib = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
+#ifdef DIRT_TRACE
+    long long st_t[8]; int st_n = 0;
+    const long long st_wall0 = wall_clock64();
+#endif
+    SETUP_MARK();  // 0 start
+    const int f = chunk * STHREADS + lane;
+    const bool have = f < g.F;
+    const float* __restrict__ verts = g.vertices + (size_t)ib * g.V * 4;
+    int32_t idx[3] = {0, 0, 0};
+    float4 vv[3];
+    if (have) face_fetch_indices(g.faces + (g.shared_faces ? (size_t)f : (size_t)ib * g.F + f) * 3, idx);
+    for (int i = lane; i <= MAX_BINS; i += STHREADS) s_mask[i] = 0ull;
+    if (have) face_fetch_vertices(verts, g.V, idx, vv);
+    __syncthreads();
+    SETUP_MARK();  // 1 cleared, face requested
+    if (have) {
+        const size_t n = (size_t)ib * g.F + f;
+        FaceRec rec;
+        FaceBox box;
+        if (setup_face_from(vv, idx, g.V, g.H, g.W, rec, box)) {
+            g.recs[n] = rec;
+            const unsigned long long bit = 1ull << lane;
+            int bx0, bx1, by0, by1;
+            if (bin_range(box, g.grid, bx0, bx1, by0, by1)) {
+                for (int by = by0; by <= by1; ++by)
+                    for (int bx = bx0; bx <= bx1; ++bx) atomicOr(&s_mask[by * g.grid.bins_x + bx], bit);
+            } else {
+                atomicOr(&s_mask[MAX_BINS], bit);
+            }
+            BinEntry e;
+            e.box = box; e.face = f; e.pad = 0;
+            g.entries[((size_t)ib * g.nchunk + chunk) * (5 * (size_t)g.chunk_faces) + lane] = e;
+        } else {
+            g.recs[n].flags = 0;   // (no bit anywhere: its entry slot is never read)
+        }
+    }
+    SETUP_MARK();  // 2 pass 1 done (set-up + masks + entry)
+    __syncthreads();
+    SETUP_MARK();  // 3
+    // the directory is stored bin-major, [bin][chunk]: what a raster tile reads -- its bin's cell of every chunk -- is contiguous
+    BinCell* __restrict__ col = g.cells + (size_t)ib * (MAX_BINS + 1) * g.nchunk + chunk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned long long m = s_mask[4 * lane + i];
+        col[(size_t)(4 * lane + i) * g.nchunk] = BinCell{(uint32_t)m, (uint32_t)(m >> 32)};
+    }
+    if (lane == STHREADS - 1) {
+        const unsigned long long m = s_mask[MAX_BINS];
+        col[(size_t)MAX_BINS * g.nchunk] = BinCell{(uint32_t)m, (uint32_t)(m >> 32)};
+    }
+    SETUP_MARK();  // 4 directory done
+    SETUP_MARK();  // 5 (no second pass)
+#ifdef DIRT_TRACE
+    if (lane == 0 && g_trace_setup) {
+        long long* o = g_trace_setup + (size_t)blockIdx.x * 16;
+        for (int i = 0; i < 8; ++i) o[i] = i < st_n ? st_t[i] : 0;
+        o[8] = st_wall0; o[9] = (long long)wall_clock64() - st_wall0;
+    }
+#endif
+}
+
 // A tile is 2 x 2 wave regions; a wave region is NB x NB blocks of 8 x 8 pixels (NB * NB pixels per lane).
 // NB = 2 (32 x 32 tiles, one record fetch serves 256 pixels) is the normal shape; NB = 1 (16 x 16 tiles) gives four
 // times as many workgroups for small frames, where 32 x 32 tiles would leave most of the 1024 SIMDs idle.
@@ -433,16 +504,21 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
     const BinCell* __restrict__ cells = p.cells + (size_t)ib * p.nchunk * (MAX_BINS + 1);
     const BinEntry* __restrict__ scene_entries = p.entries + (size_t)ib * p.nchunk * (5 * (size_t)p.chunk_faces);
     const int nruns = 2 * p.nchunk;  // <= 512: two per thread
+    // (masked directory -- chunks of 64 faces, setup_kernel_masked --: a cell is the mask of the chunk's faces in the bin, and
+    // face l of the chunk has entry l of the chunk's segment; otherwise start / count of a run inside the segment)
+    const bool masked = p.masked != 0;
     uint32_t run_base[2], run_count[2], run_pos[2];
+    unsigned long long run_mask[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int j = tid + k * RTHREADS;
-        run_base[k] = 0; run_count[k] = 0; run_pos[k] = 0;
+        run_base[k] = 0; run_count[k] = 0; run_pos[k] = 0; run_mask[k] = 0ull;
         if (j < nruns) {
             const int c = j < p.nchunk ? j : j - p.nchunk;
             const BinCell cell = cells[(size_t)(j < p.nchunk ? bin : MAX_BINS) * p.nchunk + c];
-            run_base[k] = (uint32_t)c * (5u * (uint32_t)p.chunk_faces) + cell.start;
-            run_count[k] = cell.count;
+            run_base[k] = (uint32_t)c * (5u * (uint32_t)p.chunk_faces) + (masked ? 0u : cell.start);
+            run_count[k] = masked ? 0u : cell.count;
+            run_mask[k] = masked ? ((unsigned long long)cell.count << 32) | (unsigned long long)cell.start : 0ull;
         }
     }
 
@@ -484,14 +560,26 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
         //      trip's hits of the whole wave claim their list slots with ONE wave-aggregated LDS atomic (rounds 1-3: one per
         //      entry, i.e. four dependent LDS round trips per trip behind nested divergent branches) ----
         bool full = false;
-        uint32_t touch = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            while (run_pos[k] < run_count[k] && !full) {
+            while ((masked ? run_mask[k] != 0ull : run_pos[k] < run_count[k]) && !full) {
                 BinEntry en[4];
-                const uint32_t left = run_count[k] - run_pos[k];
+                uint32_t left, at[4];   // entries left in the run; where the next four are
+                if (masked) {
+                    unsigned long long t = run_mask[k];
+                    left = (uint32_t)__popcll(t);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) en[i] = scene_entries[run_base[k] + run_pos[k] + min((uint32_t)i, left - 1u)];
+                    for (int i = 0; i < 4; ++i) {
+                        at[i] = t != 0ull ? (uint32_t)(__ffsll((long long)t) - 1) : (i ? at[i - 1] : 0u);   // (past the last: the last again; not a hit)
+                        t &= t - 1ull;
+                    }
+                } else {
+                    left = run_count[k] - run_pos[k];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) at[i] = run_pos[k] + min((uint32_t)i, left - 1u);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) en[i] = scene_entries[run_base[k] + at[i]];
                 bool hit[4];
                 unsigned long long hm[4];
                 uint32_t before = 0, off[4];
@@ -530,18 +618,18 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
                         const uint32_t rows = UNIT & ((2u << (BT * by1 + BT - 1)) - (1u << (BT * by0)));
                         s_face[slot] = en[i].face;
                         s_mask[slot] = (uint16_t)(rowbits * rows);
-                        // the staging pass reads this face's set-up record (one 128-byte line, written by another XCD's
-                        // set-up workgroup) after the list barrier: touch it now, so that it is on its way to this
-                        // XCD's L2 while the list is still being built.  The loaded word is never used; `touch` stays
-                        // live until the wait below, so that its register is not reused while loads are in flight.
-                        asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(recs + en[i].face));
                     }
                 }
-                run_pos[k] += consumed;
+                if (masked) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if ((uint32_t)i < consumed) run_mask[k] &= run_mask[k] - 1ull;   // strike the consumed faces off
+                } else {
+                    run_pos[k] += consumed;
+                }
             }
         }
         TRACE_MARK();  // 3: appended
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(touch));
         __syncthreads();
         const int n = (int)min(s_count, (uint32_t)LIST_CAP);
         if (round != 0) lds_records = false;
@@ -620,7 +708,7 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
             TRACE_ACC(3);
         }
         // another round? (a thread whose append found the list full still holds entries)
-        const bool more = (run_pos[0] < run_count[0]) | (run_pos[1] < run_count[1]);
+        const bool more = masked ? ((run_mask[0] | run_mask[1]) != 0ull) : ((run_pos[0] < run_count[0]) | (run_pos[1] < run_count[1]));
         if (!__syncthreads_or(more)) break;
     }
 
@@ -822,7 +910,8 @@ hipError_t launch_geometry(const GeomParams& g, hipStream_t stream)
     if (g.B == 0) return hipSuccess;
     // also with F == 0: the (all-zero) directory row is what the raster kernel reads
     const dim3 grid((unsigned)g.nchunk, (unsigned)g.B);
-    if (g.chunk_faces > STHREADS) hipLaunchKernelGGL(setup_kernel<4>, grid, dim3(4 * STHREADS), 0, stream, g);
+    if (g.masked) hipLaunchKernelGGL(setup_kernel_masked, grid, dim3(STHREADS), 0, stream, g);
+    else if (g.chunk_faces > STHREADS) hipLaunchKernelGGL(setup_kernel<4>, grid, dim3(4 * STHREADS), 0, stream, g);
     else hipLaunchKernelGGL(setup_kernel<1>, grid, dim3(STHREADS), 0, stream, g);
     return hipGetLastError();
 }
