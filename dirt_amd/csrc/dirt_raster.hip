@@ -271,6 +271,14 @@ __global__ __launch_bounds__(STHREADS) void setup_kernel_masked(GeomParams g)
 constexpr int RTHREADS = 256;     // 4 waves: one per region
 constexpr int LIST_CAP = 1024;    // candidates listed per round
 constexpr int SHADE_CAP = 96;     // candidates whose set-up record (and vertex colours) stay in LDS for the shading pass
+struct alignas(8) ShadeRec {      // the part of a FaceRec the shading pass reads, 104 bytes
+    double coef[9];
+    double inv_det;
+    uint32_t flags;
+    int32_t vid[3];
+    double pad;
+};
+static_assert(sizeof(ShadeRec) == 104, "ShadeRec is 26 dwords");
 
 // What the coverage / depth loop reads per candidate: built once per (tile, candidate) by one lane when the
 // candidate is staged in LDS, 80 bytes = five 16-byte LDS reads.
@@ -467,7 +475,10 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
     __shared__ uint16_t s_mask[LIST_CAP];  // bit (BT*by + bx): the face's box touches block (bx, by) of the tile
     __shared__ uint32_t s_count;
     __shared__ TileRec s_rec[64];          // tile-local records of the 64 list entries being rasterised
-    __shared__ FaceRec s_shade[SHADE_CAP]; // the set-up records of the first listed candidates, for the shading pass
+    // what the shading pass needs of the set-up records of the first listed candidates: 96 of a record's 128 bytes, at a
+    // stride of 104 (26 dwords) -- lanes of a wave read the SAME field of DIFFERENT candidates' records, which at a stride of
+    // 128 bytes is the same two banks for every candidate (round 5: SHADE_STRIDE; the records took 12.3 KB, now 9.75)
+    __shared__ __align__(8) ShadeRec s_shade[SHADE_CAP];
     __shared__ float4 s_col[LDS_COLORS ? SHADE_CAP : 1][3];  // ... and their vertex colours (channel-specialised kernels)
     // any channel count that is a multiple of 4, up to 16: the colours of the first QCAP listed candidates, [candidate][vertex][quad]
     constexpr bool LDS_QUADS = MODE == 0 && CSPEC == 0;
@@ -650,7 +661,13 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
                 const FaceRec rec = recs[face];
                 make_tile_rec(rec, face, (double)tx0 + 0.5, (double)(p.H - 1 - tr0) + 0.5, wf, hf, &s_rec[tid]);
                 if (round == 0 && cb + tid < SHADE_CAP) {
-                    s_shade[cb + tid] = rec;
+                    {
+                        ShadeRec sr;
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) sr.coef[i] = rec.coef[i];
+                        sr.inv_det = rec.inv_det; sr.flags = rec.flags; sr.vid[0] = rec.vid[0]; sr.vid[1] = rec.vid[1]; sr.vid[2] = rec.vid[2]; sr.pad = 0.0;
+                        s_shade[cb + tid] = sr;
+                    }
                     if (LDS_COLORS) {
                         stage_colors = true;
                         const float* __restrict__ cols = p.vertex_colors + (size_t)ib * p.V * C;
