@@ -94,6 +94,43 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None):
     return lib_path
 
 
+def kernel_resources(extra_flags=()):
+    """{demangled kernel name: {'vgpr', 'sgpr', 'scratch', 'occupancy', 'lds'}} of every kernel of the library, from hipcc's
+    -Rpass-analysis=kernel-resource-usage (every source recompiled with the flags build_library gives it, in parallel; no GPU
+    needed).  tools/kernel_resources.sh prints it; tests/test_boundary.py asserts that no kernel uses scratch memory."""
+    import re
+    import tempfile
+    procs = []
+    tmp = tempfile.mkdtemp(prefix='dirt_res_')
+    for src in SOURCES:
+        cmd = [hipcc_path()] + [f for f in HIPCC_FLAGS if f != '-shared'] + PER_SOURCE_FLAGS.get(src, []) + list(extra_flags) + \
+              ['-c', os.path.join(CSRC, src), '-o', os.path.join(tmp, src + '.o'), '-Rpass-analysis=kernel-resource-usage']
+        procs.append(subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True))
+    rows = {}
+    for pr in procs:
+        err = pr.communicate()[1]
+        if pr.returncode != 0:
+            raise RuntimeError('hipcc failed:\n' + err[-2000:])
+        cur = None
+        for line in err.splitlines():
+            m = re.search(r'remark:\s+(.*?)\s*\[-Rpass', line)
+            if not m:
+                continue
+            t = m.group(1)
+            if t.startswith('Function Name:'):
+                cur = t.split(':', 1)[1].strip()
+                rows[cur] = {}
+            elif cur and ':' in t:
+                k, v = t.split(':', 1)
+                rows[cur][k.strip()] = v.strip()
+    out = {}
+    for mangled, r in rows.items():
+        name = subprocess.run(['c++filt', mangled], capture_output=True, text=True).stdout.strip().split('(')[0]
+        out[name] = {'vgpr': int(r.get('VGPRs', -1)), 'sgpr': int(r.get('TotalSGPRs', -1)), 'scratch': int(r.get('ScratchSize [bytes/lane]', -1)),
+                     'occupancy': int(r.get('Occupancy [waves/SIMD]', -1)), 'lds': int(r.get('LDS Size [bytes/block]', -1))}
+    return out
+
+
 if __name__ == '__main__':
     # python -m dirt_amd.build [--force] [--out path.so] [--flags "-DX=1 ..."]
     argv = sys.argv[1:]

@@ -198,3 +198,22 @@ def test_state_gradient_accumulator_layout(lib):
         assert (s1.value, s2.value) == (want, want)
         assert gv.value % 16 == 0 and gvc.value == gv.value + 16    # colours 16 bytes behind the positions of the same vertex
         assert gv.value + B * V * want * 4 <= base + n
+
+
+def test_no_kernel_uses_scratch_memory_and_the_big_kernels_keep_their_occupancy():
+    """Scratch (register spills) is ruinous on this path -- round 5 measured 27 -> 35 us and 414 -> 564 us for kernels with
+    32-96 bytes of it (profiles/EXPERIMENTS.md) -- and a register more than the bound costs a wave per SIMD: every kernel
+    of the library compiles to 0 bytes of scratch, the headline's kernels to four workgroups per compute unit (<= 128 VGPRs,
+    <= 40 KB of LDS), the two-pixels-per-lane gradient kernel to five (4 channels) and eight (1, 3 channels)."""
+    from dirt_amd import build
+    res = build.kernel_resources()
+    assert len(res) >= 40, sorted(res)
+    spilling = {k: v['scratch'] for k, v in res.items() if v['scratch'] != 0}
+    assert not spilling, spilling
+    for name, v in res.items():
+        if 'raster_kernel' in name or ('grad_kernel<' in name and 'grad_kernel<6' not in name):
+            assert v['vgpr'] <= 128 and v['lds'] <= 40960, (name, v)
+    assert res['void dirt::grad_kernel_px2<4, false>']['vgpr'] <= 96 and res['void dirt::grad_kernel_px2<4, false>']['lds'] <= 27306
+    for c in (1, 3):
+        v = res['void dirt::grad_kernel_px2<%d, false>' % c]
+        assert v['vgpr'] <= 64 and v['lds'] <= 20480, (c, v)
