@@ -976,10 +976,11 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
         //   K3-3ch                    1024        22.2        23.1       (64 VGPRs: seven workgroups per compute unit)
         //   K3-1ch                    1024        20.6        18.9
         //   K3-2048 (4 ch)            4096        72.9        68.2       rounds overlap by themselves; px2's extra atomics and instructions cost
-        // Rule: more than one workgroup per compute unit but less than a full round of the 4-pixel kernel; 3 channels up to a full round.
+        //   K5-3ch  (50 000 faces)    4096        62.2        66.5       3 channels: eight workgroups per compute unit
+        // Rule: more than one workgroup per compute unit but less than a full round of the 4-pixel kernel; 3 channels: every such frame.
         const bool px2_ok = p.C == 1 || p.C == 3 || (p.C == 4 && p.pixels_aligned16);
         const long long wgs32 = (long long)ntiles * p.B;
-        bool px2 = px2_ok && !few_tiles && (wgs32 < 1024 || (p.C == 3 && wgs32 <= 1024));
+        bool px2 = px2_ok && !few_tiles && (wgs32 < 1024 || p.C == 3);
         if (p.flags & DIRT_FLAG_GRAD_PX2) px2 = px2_ok;
         if (p.flags & (DIRT_FLAG_GRAD_ROWS | DIRT_FLAG_GRAD_PAIRS | DIRT_FLAG_GRAD_PX4)) px2 = false;
         if (px2) return launch_grad_px2(p, stream);

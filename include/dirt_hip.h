@@ -89,8 +89,8 @@ extern "C" {
                                         summation order */
 #define DIRT_FLAG_GRAD_PX2 0x8000u   /* ... or the two-pixels-per-lane gradient kernel on 32x16 tiles (channel counts 1, 3, 4:
                                         twice the waves at half the instruction chain each; chosen by the library for frames
-                                        of more than 256 and fewer than 1024 32x32 tiles -- 3 channels: up to 1024 -- where
-                                        it measured faster).  Same results to summation order */
+                                        of more than 256 and fewer than 1024 32x32 tiles -- 3 channels: of more than 256 --
+                                        where it measured faster).  Same results to summation order */
 #define DIRT_FLAG_GRAD_PX4 0x10000u  /* ... or the four-pixels-per-lane kernel (rows or pairs by the library's own rule) where
                                         the library would choose the two-pixels-per-lane one */
 #define DIRT_FLAG_SHARED_FACES 0x800u /* `faces` is one [F,3] topology shared by all B scenes instead of [B,F,3] (the
