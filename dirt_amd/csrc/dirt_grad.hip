@@ -45,6 +45,12 @@ namespace dirt {
 #ifndef DIRT_GBK_COALESCED
 #define DIRT_GBK_COALESCED 1
 #endif
+#ifndef DIRT_ALIAS_INBOX
+#define DIRT_ALIAS_INBOX 1
+#endif
+#ifndef DIRT_TWO3_WAVES
+#define DIRT_TWO3_WAVES (DIRT_ALIAS_INBOX ? 4 : 3)   // waves per SIMD the {3,3} many-channel shape is register-allocated for
+#endif
 #ifdef DIRT_TRACE
 // Per-wave phase timestamps (s_memtime) for tools/trace_grad.py; compiled only into the tracing build of the library.
 __device__ long long* g_trace_grad = nullptr;
@@ -86,14 +92,21 @@ constexpr int RING = 2 * 34 + 2 * 8;    // ring cells: what the wave's pixels se
 // where the pairs of rows need ~6.4, but ~1.6 x the float atomics: launched where the memory system has room for them
 // (small frames); otherwise the two rows of a pair (16 x 8 pixels) work on one face.
 template <int CSPEC, bool STRIDED, bool DEBUG, bool ROWS = false>
-__global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(GradParams p)
+__global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? DIRT_TWO3_WAVES : 4) void grad_kernel(GradParams p)
 {
     static_assert(CSPEC == 1 || CSPEC == 3 || CSPEC == 4 || (CSPEC == 6 && STRIDED), "pass shapes");
     constexpr int NPLANES = CSPEC;
     constexpr int PC = CSPEC == 6 ? 6 : 4;   // channels a staging item holds
     __shared__ __align__(16) float s_pix[NPLANES][PR][PS];  // the pass's channels of `pixels`, edge clamped
     __shared__ __align__(16) float2 s_vw[PR][VS];           // {clip_w, face} of every pixel of the halo'd tile
-    __shared__ __align__(16) float2 s_inbox[GTHREADS / 64][ICELLS];  // per wave: (fx, fy) sent to each pixel of its region + ring
+    // per wave: (fx, fy) sent to each pixel of its region + ring.  The {3,3} shape (six planes) ALIASES it -- and the ring cells'
+    // factors, which the face loop reads only in a rare branch -- onto the planes, which are dead once every wave has its Scharr
+    // responses (a workgroup barrier there): 50 -> 39 KB of LDS and twelve registers less, so that FOUR workgroups share a
+    // compute unit instead of three for the many-channel frames, whose gradient is bound by memory requests in flight
+    constexpr bool ALIAS_INBOX = DIRT_ALIAS_INBOX && CSPEC == 6;
+    __shared__ __align__(16) float2 s_inbox_own[ALIAS_INBOX ? 1 : GTHREADS / 64][ALIAS_INBOX ? 1 : ICELLS];
+    constexpr int RING_FLOATS = 2 * 6 * 64;   // per wave: [cell e][component: b0 b1 b2 fx fy fw][lane]
+    static_assert(!ALIAS_INBOX || sizeof(float2) * (GTHREADS / 64) * ICELLS + sizeof(float) * (GTHREADS / 64) * RING_FLOATS <= sizeof(float) * NPLANES * PR * PS, "inboxes + ring factors fit in the planes");
 
 #ifdef DIRT_TRACE
     long long tr_t[12]; int tr_n = 0; long long tr_c[4] = {0, 0, 0, 0};
@@ -172,7 +185,8 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
         in_px[j] = (xs + j < W) & (y < H);
         interior[j] = in_px[j] & (xs + j > 0) & (y > 0) & (xs + j < W - 1) & (y < H - 1);
     }
-    float2* const inbox = &s_inbox[wave][0];
+    float2* const inbox = ALIAS_INBOX ? reinterpret_cast<float2*>(&s_pix[0][0][0]) + wave * ICELLS : &s_inbox_own[ALIAS_INBOX ? 0 : wave][0];
+    float* const ringstore = reinterpret_cast<float*>(reinterpret_cast<float2*>(&s_pix[0][0][0]) + (GTHREADS / 64) * ICELLS) + wave * RING_FLOATS + lane;
     const int my_cell = (ry + 1) * IS + 4 * sx + 2;   // the strip's first pixel in the inbox
 
     // ---- staging: loads of the pass's channels of the pixels tile (+halo), edge clamped (at(), :113-124).  A thread
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
     float bk[4][3];
 #pragma unroll
     for (int j = 0; j < 4; ++j) decode_bary(ld_off<float2>(state_b, in_px[j] ? (own_rel + (uint32_t)j) * 8u : 0u), bk[j]);
-    zero_inbox();
+    if (!ALIAS_INBOX) zero_inbox();
 
     // (fx, fy) sent to this strip's own pixels by themselves (see "position factors" below)
     using std::integral_constant;
@@ -288,15 +302,21 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
     auto face_loop = [&](auto nchv_tag, const auto& g, const int (&key)[4], const bool (&covered)[4],
                          const float2v (&fpos_xy)[4], const float (&fpos_w)[4], const int (&lkey)[2], const float (&lb)[2][3], const float (&lf)[2][3]) {
         constexpr int NCHV = decltype(nchv_tag)::value;
-        constexpr int S = (3 + NCHV + 1) & ~1;      // values per vertex (padded to whole pairs)
+        // FWS (the {3,3} shape with the aliased inbox): an even channel count leaves the w factor alone in its pair -- g.., fx, fy,
+        // fw, 0 -- and the padding costs a register per pixel and per vertex sum.  There fw travels as a SCALAR next to the pairs
+        // (one v_fma_f32 instead of one v_pk_fma_f32 per pixel and vertex: the same instruction count) and its three sums
+        // follow the vertices' blocks in the reduction's input: 9 registers less in a loop that has to fit 128.
+        constexpr bool FWS = ALIAS_INBOX && NCHV == 6;
+        constexpr int S = FWS ? NCHV + 2 : (3 + NCHV + 1) & ~1;      // values per vertex held in pairs (padded to whole pairs)
         constexpr int HP = S / 2;                   // ... as pairs
-        constexpr int NV = 3 * S;                   // values per face
+        constexpr int NV = FWS ? 3 * S + 3 : 3 * S; // values per face
         constexpr int NR = NV <= 16 ? 16 : (NV <= 24 ? 24 : 32);   // ... padded to what the row reduction takes
         static_assert(NV <= NR, "");
         // Order of a vertex's values: the colours first (they arrive as whole registers of the grad_pixels loads), then
-        // the position factors with (fx, fy) as one aligned pair: NCHV even: g.., fx, fy, fw, 0;  odd: g.., fw, fx, fy.
-        constexpr int IW = (NCHV & 1) ? NCHV : NCHV + 2, IX = (NCHV & 1) ? NCHV + 1 : NCHV, IY = IX + 1;
-        static_assert((IX & 1) == 0 && IY < S && IW < S, "");
+        // the position factors with (fx, fy) as one aligned pair: NCHV even: g.., fx, fy, fw, 0;  odd: g.., fw, fx, fy
+        // (FWS: g.., fx, fy per vertex, then fw of the three vertices: IW = S marks "not in the pairs").
+        constexpr int IW = FWS ? S : ((NCHV & 1) ? NCHV : NCHV + 2), IX = (NCHV & 1) ? NCHV + 1 : NCHV, IY = IX + 1;
+        static_assert((IX & 1) == 0 && IY < S && (FWS || IW < S), "");
         // this lane's roles: it adds the row totals of values rv[0], rv[1] of the row's face (row_value_of_lane): vertex
         // rv / S, component c = rv % S: c < NCHV: colour c; IX, IY, IW: (x, y, w) of grad_vertices
         // Pairs of rows: the two rows end up with the same totals -- see the end of an iteration -- so the even row sends
@@ -313,8 +333,9 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
 #pragma unroll
         for (int e = 0; e < NROLES; ++e) {
             const int v = rv[e];
-            const int c = v >= 0 ? v % S : S;
-            role_k[e] = v >= 0 && v < NV ? v / S : 0;
+            const bool w_tail = FWS && v >= 3 * S && v < NV;           // (FWS: the three fw sums behind the vertices' blocks)
+            const int c = w_tail ? IW : (v >= 0 && v < 3 * S ? v % S : S + 1);
+            role_k[e] = w_tail ? v - 3 * S : (v >= 0 && v < 3 * S ? v / S : 0);
             const bool is_pos = c == IX || c == IY || c == IW;
             role_valid[e] = v >= 0 && v < NV && (c < NCHV || is_pos);
             role_base[e] = is_pos ? grad_vertices + (c == IW ? 3 : c - IX) : grad_vertex_colors + (c < NCHV ? c : 0);
@@ -322,12 +343,14 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
         }
         // the factors of a pixel, in pairs
         float2v fp[4][HP];
+        float fpw[4];   // (FWS: the w factor of a pixel)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float f[S];
+            float f[S + 1];
 #pragma unroll
             for (int c = 0; c < S; ++c) f[c] = c < NCHV ? g[j][c < NCHV ? c : 0] : 0.f;
             f[IW] = fpos_w[j];
+            fpw[j] = FWS ? fpos_w[j] : 0.f;
 #pragma unroll
             for (int h = 0; h < HP; ++h) { fp[j][h].x = f[2 * h]; fp[j][h].y = f[2 * h + 1]; }
             fp[j][IX / 2] = fpos_xy[j];
@@ -346,6 +369,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
             float2v t = fp[j][0];
 #pragma unroll
             for (int h = 1; h < HP; ++h) t += fp[j][h];
+            if (FWS) t.x += fpw[j];
             const float u = (t.x + t.y) + ((bk[j][0] + bk[j][1]) + bk[j][2]);   // non-finite iff a factor is, or the sum overflows
             const bool bad = !__builtin_isfinite(u);
             pend[j] = bad ? NONE : (uint32_t)key[j];
@@ -357,9 +381,9 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
 #pragma unroll
-                            for (int c = 0; c < S; ++c) {
+                            for (int c = 0; c < S + (FWS ? 1 : 0); ++c) {
                                 if (!(c < NCHV || c == IX || c == IY || c == IW) || (STRIDED && NCHV == 4 && !single_on && c == 3) || (NCHV == 6 && c < NCHV && c >= nch_live)) continue;
-                                const float val = bk[j][k] * ((c & 1) ? fp[j][c / 2].y : fp[j][c / 2].x);
+                                const float val = bk[j][k] * ((FWS && c == IW) ? fpw[j] : ((c & 1) ? fp[j][(c < S ? c : 0) / 2].y : fp[j][(c < S ? c : 0) / 2].x));
                                 float* dstp = c >= NCHV && (c == IX || c == IY || c == IW)
                                     ? reinterpret_cast<float*>(reinterpret_cast<char*>(grad_vertices) + (size_t)((uint32_t)vk[k] * gv_row_bytes)) + (c == IW ? 3 : c - IX)
                                     : reinterpret_cast<float*>(reinterpret_cast<char*>(grad_vertex_colors) + (size_t)((uint32_t)vk[k] * gvc_row_bytes)) + c;
@@ -368,10 +392,15 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
                     }
 #pragma unroll
                     for (int h = 0; h < HP; ++h) fp[j][h] = float2v{0.f, 0.f};
+                    fpw[j] = 0.f;
                 }
             }
         }
+#ifdef DIRT_KO_RING   // (knock-out build, timing only: ring cells' contributions dropped -- what the loop costs without their registers)
+        pend[4] = NONE; pend[5] = NONE;
+#else
         pend[4] = (uint32_t)lkey[0]; pend[5] = (uint32_t)lkey[1];
+#endif
         // the row's next face: the smallest pending key of its 16 lanes (an all-lanes minimum by four DPP rotations)
         auto next_face = [&]() {
             uint32_t K = min(min(min(pend[0], pend[1]), min(pend[2], pend[3])), min(pend[4], pend[5]));
@@ -398,8 +427,9 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
 #pragma unroll
             for (int e = 0; e < NROLES; ++e) vsel[e] = ld_off<int32_t>(faces, fbase + 4u * (uint32_t)role_k[e]);
             float2v accp[NR / 2];
+            float accw[3] = {0.f, 0.f, 0.f};   // (FWS: the w sums of the three vertices)
 #pragma unroll
-            for (int i = NV / 2; i < NR / 2; ++i) accp[i] = float2v{0.f, 0.f};
+            for (int i = (FWS ? 3 * HP : NV / 2); i < NR / 2; ++i) accp[i] = float2v{0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool m = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(pend[j] == K) & live);
@@ -410,28 +440,44 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
 #pragma unroll
                     for (int h = 0; h < HP; ++h)
                         accp[k * HP + h] = j == 0 ? pk_mul_scalar(bm, fp[j][h]) : pk_fma_scalar(bm, fp[j][h], accp[k * HP + h]);
+                    if (FWS) accw[k] = j == 0 ? bm * fpw[j] : fmaf(bm, fpw[j], accw[k]);
                 }
             }
+#ifndef DIRT_KO_RING
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const lanemask mm = __builtin_amdgcn_ballot_w64(pend[4 + e] == K) & live;
                 if (mm != 0ull) {
                     const bool m = __builtin_amdgcn_inverse_ballot_w64(mm);
                     pend[4 + e] = m ? NONE : pend[4 + e];
+                    float rb[3], rf[3];
+                    if constexpr (ALIAS_INBOX) {   // (the cell's factors were parked in LDS by gather_positions: read here, where a cell's face comes up)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { rb[c] = m ? ringstore[(e * 6 + c) * 64] : 0.f; rf[c] = m ? ringstore[(e * 6 + 3 + c) * 64] : 0.f; }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { rb[c] = lb[e][c]; rf[c] = lf[e][c]; }
+                    }
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const float bm = m ? lb[e][k] : 0.f;
-                        accp[k * HP + IX / 2] = pk_fma_scalar(bm, float2v{lf[e][0], lf[e][1]}, accp[k * HP + IX / 2]);
-                        if (IW & 1) accp[k * HP + IW / 2].y = fmaf(bm, lf[e][2], accp[k * HP + IW / 2].y);
-                        else accp[k * HP + IW / 2].x = fmaf(bm, lf[e][2], accp[k * HP + IW / 2].x);
+                        const float bm = m ? rb[k] : 0.f;
+                        accp[k * HP + IX / 2] = pk_fma_scalar(bm, float2v{rf[0], rf[1]}, accp[k * HP + IX / 2]);
+                        if (FWS) accw[k] = fmaf(bm, rf[2], accw[k]);
+                        else if (IW & 1) accp[k * HP + (FWS ? 0 : IW / 2)].y = fmaf(bm, rf[2], accp[k * HP + (FWS ? 0 : IW / 2)].y);
+                        else accp[k * HP + (FWS ? 0 : IW / 2)].x = fmaf(bm, rf[2], accp[k * HP + (FWS ? 0 : IW / 2)].x);
                     }
                 }
             }
+#endif
             GCOUNT(1, 1);
             const uint32_t K_next = next_face();
             float acc[NR];
 #pragma unroll
             for (int i = 0; i < NR / 2; ++i) { acc[2 * i] = accp[i].x; acc[2 * i + 1] = accp[i].y; }
+            if (FWS) {   // the three w sums behind the vertices' blocks (values 3 S .. 3 S + 2)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[3 * S + k] = accw[k];
+            }
             float d0, d1;
             row_reduce_scatter<NR>(acc, lane, d0, d1);
             if (!ROWS) {   // the two rows of a pair worked on the same face: their totals, added (both rows get the sum)
@@ -514,6 +560,12 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
                         }
                         lkey[e] = -1;
                         lb[e][0] = 0.f; lb[e][1] = 0.f; lb[e][2] = 0.f; lf[e][0] = 0.f; lf[e][1] = 0.f; lf[e][2] = 0.f;
+                    }
+                    if constexpr (ALIAS_INBOX) {   // park the cell's factors (the loop reads them back where its face comes up)
+                        if (lkey[e] >= 0) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) { ringstore[(e * 6 + c) * 64] = lb[e][c]; ringstore[(e * 6 + 3 + c) * 64] = lf[e][c]; }
+                        }
                     }
                 }
             }
@@ -704,6 +756,10 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? 3 : 4) void grad_kernel(Grad
             }
         }
         GMARK();  // 4 Scharr done
+        if (ALIAS_INBOX) {   // every wave is done with the planes: they become the inboxes
+            __syncthreads();
+            zero_inbox();
+        }
 
         // ---- the strip and its eight neighbours: clip_w and face ----
         float w_own[4], w_up[4], w_dn[4], w_l, w_r;
