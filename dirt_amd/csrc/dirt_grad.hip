@@ -91,8 +91,11 @@ constexpr int RING = 2 * 34 + 2 * 8;    // ring cells: what the wave's pixels se
 // ROWS: every DPP row (8 x 8 pixels) of a wave walks its own faces -- four faces per face-loop iteration, ~5 iterations
 // where the pairs of rows need ~6.4, but ~1.6 x the float atomics: launched where the memory system has room for them
 // (small frames); otherwise the two rows of a pair (16 x 8 pixels) work on one face.
-template <int CSPEC, bool STRIDED, bool DEBUG, bool ROWS = false>
-__global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? DIRT_TWO3_WAVES : 4) void grad_kernel(GradParams p)
+// AI: the per-wave inbox and the ring cells' factors ALIASED onto the pixel planes (always for the {3,3} shape, CSPEC = 6): one more
+// workgroup barrier, 11 KB of LDS and twelve registers less -- one workgroup more per compute unit, which pays when the grid
+// takes several rounds (launch_grad).
+template <int CSPEC, bool STRIDED, bool DEBUG, bool ROWS = false, bool AI = false>
+__global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? DIRT_TWO3_WAVES : (AI ? 5 : 4)) void grad_kernel(GradParams p)
 {
     static_assert(CSPEC == 1 || CSPEC == 3 || CSPEC == 4 || (CSPEC == 6 && STRIDED), "pass shapes");
     constexpr int NPLANES = CSPEC;
@@ -103,10 +106,14 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? DIRT_TWO3_WAVES : 4) void gr
     // factors, which the face loop reads only in a rare branch -- onto the planes, which are dead once every wave has its Scharr
     // responses (a workgroup barrier there): 50 -> 39 KB of LDS and twelve registers less, so that FOUR workgroups share a
     // compute unit instead of three for the many-channel frames, whose gradient is bound by memory requests in flight
-    constexpr bool ALIAS_INBOX = DIRT_ALIAS_INBOX && CSPEC == 6;
+    static_assert(!AI || (CSPEC == 4 && !STRIDED && !DEBUG && !ROWS), "the aliased form exists for the plain 4-channel kernel (and the {3,3} shape)");
+    constexpr bool ALIAS_INBOX = DIRT_ALIAS_INBOX && (CSPEC == 6 || AI);
     __shared__ __align__(16) float2 s_inbox_own[ALIAS_INBOX ? 1 : GTHREADS / 64][ALIAS_INBOX ? 1 : ICELLS];
-    constexpr int RING_FLOATS = 2 * 6 * 64;   // per wave: [cell e][component: b0 b1 b2 fx fy fw][lane]
-    static_assert(!ALIAS_INBOX || sizeof(float2) * (GTHREADS / 64) * ICELLS + sizeof(float) * (GTHREADS / 64) * RING_FLOATS <= sizeof(float) * NPLANES * PR * PS, "inboxes + ring factors fit in the planes");
+    // (the ring cells' factors are parked in the wave's OWN inbox once gather_positions has read it: cell 0 of the 64 lanes,
+    // [component: b0 b1 b2 fx fy fw][lane], then cell 1 of lanes 0 .. 19: 504 floats of the inbox's 688)
+    constexpr int RING_E1 = 6 * 64, RING_E1_LANES = RING - 64;
+    static_assert(RING_E1 + 6 * RING_E1_LANES <= 2 * ICELLS, "the ring factors fit in the inbox");
+    static_assert(!ALIAS_INBOX || sizeof(float2) * (GTHREADS / 64) * ICELLS <= sizeof(float) * NPLANES * PR * PS, "the inboxes fit in the planes");
 
 #ifdef DIRT_TRACE
     long long tr_t[12]; int tr_n = 0; long long tr_c[4] = {0, 0, 0, 0};
@@ -186,7 +193,8 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? DIRT_TWO3_WAVES : 4) void gr
         interior[j] = in_px[j] & (xs + j > 0) & (y > 0) & (xs + j < W - 1) & (y < H - 1);
     }
     float2* const inbox = ALIAS_INBOX ? reinterpret_cast<float2*>(&s_pix[0][0][0]) + wave * ICELLS : &s_inbox_own[ALIAS_INBOX ? 0 : wave][0];
-    float* const ringstore = reinterpret_cast<float*>(reinterpret_cast<float2*>(&s_pix[0][0][0]) + (GTHREADS / 64) * ICELLS) + wave * RING_FLOATS + lane;
+    float* const ringstore = reinterpret_cast<float*>(inbox) + lane;
+    auto ring_at = [&](int e, int c) -> float& { return ringstore[e == 0 ? c * 64 : RING_E1 + c * RING_E1_LANES]; };
     const int my_cell = (ry + 1) * IS + 4 * sx + 2;   // the strip's first pixel in the inbox
 
     // ---- staging: loads of the pass's channels of the pixels tile (+halo), edge clamped (at(), :113-124).  A thread
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? DIRT_TWO3_WAVES : 4) void gr
                     float rb[3], rf[3];
                     if constexpr (ALIAS_INBOX) {   // (the cell's factors were parked in LDS by gather_positions: read here, where a cell's face comes up)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) { rb[c] = m ? ringstore[(e * 6 + c) * 64] : 0.f; rf[c] = m ? ringstore[(e * 6 + 3 + c) * 64] : 0.f; }
+                        for (int c = 0; c < 3; ++c) { rb[c] = m ? ring_at(e, c) : 0.f; rf[c] = m ? ring_at(e, 3 + c) : 0.f; }
                     } else {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) { rb[c] = lb[e][c]; rf[c] = lf[e][c]; }
@@ -561,14 +569,16 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? DIRT_TWO3_WAVES : 4) void gr
                         lkey[e] = -1;
                         lb[e][0] = 0.f; lb[e][1] = 0.f; lb[e][2] = 0.f; lf[e][0] = 0.f; lf[e][1] = 0.f; lf[e][2] = 0.f;
                     }
-                    if constexpr (ALIAS_INBOX) {   // park the cell's factors (the loop reads them back where its face comes up)
-                        if (lkey[e] >= 0) {
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) { ringstore[(e * 6 + c) * 64] = lb[e][c]; ringstore[(e * 6 + 3 + c) * 64] = lf[e][c]; }
-                        }
-                    }
                 }
             }
+        }
+        if constexpr (ALIAS_INBOX) {   // park the cells' factors -- after BOTH cells of every lane have been read: the store is the inbox
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (lkey[e] >= 0) {   // (cell 1: lanes 0 .. RING - 65 only)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { ring_at(e, c) = lb[e][c]; ring_at(e, 3 + c) = lf[e][c]; }
+                }
         }
         GCOUNT(0, __popcll(__builtin_amdgcn_ballot_w64(lkey[0] >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(lkey[1] >= 0)));
     };
@@ -1046,7 +1056,15 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
     if (p.flags & DIRT_FLAG_GRAD_PAIRS) rows = false;
     p.c_first = 0; p.npasses = 1; p.gbk_split = -1; p.last_second = 0;
     // the common channel counts: kernels in which the channel count is a compile-time constant
-    if (p.C == 4 && p.pixels_aligned16) DIRT_LAUNCH_GRAD(4, false);
+    if (p.C == 4 && p.pixels_aligned16) {
+        // Grids of several rounds (eight scenes of K3 in one launch: 8192 workgroups): the aliased-inbox form, five workgroups per
+        // compute unit instead of four -- K3 x 8 gradient 157.7 -> 147.7 us, K3-2048 66.4 -> 65.9; a single round pays only for its
+        // extra barrier (K3: 26.4 -> 27.8), so one scene of up to 2047 tiles keeps the plain form.
+        if (DIRT_ALIAS_INBOX && !rows && !p.debug_thingy && (long long)ntiles * p.B >= 2048)
+            hipLaunchKernelGGL((grad_kernel<4, false, false, false, true>), dim3(ntiles, (unsigned)p.B), block, dyn_lds, stream, p);
+        else
+            DIRT_LAUNCH_GRAD(4, false);
+    }
     else if (p.C == 3) DIRT_LAUNCH_GRAD(3, false);
     else if (p.C == 1) DIRT_LAUNCH_GRAD(1, false);
     else {
