@@ -425,3 +425,17 @@ def test_second_backward_over_one_forward_returns_its_own_gradients(gpu, oracle)
                                            state.data_ptr(), state.numel(), _lib.FLAG_REUSE_STATE | _lib.FLAG_OUTPUTS_CLEARED,
                                            torch.cuda.current_stream().cuda_stream))
     parity.grads_close(gv, gvc, ow, 'OUTPUTS_CLEARED on foreign tensors')
+
+
+def test_graphed_optimisation_example_reduces_the_loss(gpu):
+    """examples/fit_colors_graphed.py: a static-shape descent loop, one HIP-graph launch per iteration, parameters updated in
+    place between launches: the loss must fall substantially."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'fit_colors_graphed.py')
+    spec = importlib.util.spec_from_file_location('example_fit_colors_graphed', path)
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    history = ex.fit(gpu, steps=40, verbose=False)
+    assert np.isfinite(history).all()
+    assert history[-1] < 0.5 * history[0], (history[0], history[-1])
