@@ -3,20 +3,24 @@
 // Same contract as grad_kernel (dirt_grad.hip; replaces assemble_grads, csrc/rasterise_grad_egl.cu:93-236, for all channel
 // groups of dirt/rasterise_ops.py:145-165 in one launch), same per-pixel arithmetic and the same face loop -- other
 // decomposition.  grad_kernel gives a lane a 4 x 1 strip, a wave 32 x 8 pixels and a workgroup a 32 x 32 tile: at
-// 1024 x 1024 that is 4096 waves of ~2 900 instructions at 108 VGPRs -- exactly the chip's 4096 wave slots at that
-// register count, ONE lockstep round: every wave waits for its loads at the same time (the memory system hands them out
-// in dispatch order over ~9 us), then every wave computes while the memory system idles, and the kernel ends when the
-// last-served workgroup has worked through its chain (profiles/EXPERIMENTS.md, round 4).  Here a lane owns a 2 x 1 PAIR
-// (exactly one operand pair of the packed fp32 Scharr arithmetic), a DPP row of 16 lanes an 8 x 4 block, a wave 16 x 8
-// pixels and a workgroup (4 waves) a 32 x 16 tile: twice the waves and workgroups, each with about half the instruction
-// chain, ~22 KB of LDS and <= 96 VGPRs, so that 5-6 workgroups share a compute unit and the grid takes more than one
-// round: the loads of the later workgroups are in flight while the earlier ones compute.
+// 1024 x 1024 that is 4096 waves of ~2 900 instructions at 104-108 VGPRs -- exactly the chip's 4096 wave slots at that
+// register count, ONE lockstep round (profiles/EXPERIMENTS.md, round 4).  Here a lane owns a 2 x 1 PAIR (exactly one operand
+// pair of the packed fp32 Scharr arithmetic), a DPP row of 16 lanes an 8 x 4 block, a wave 16 x 8 pixels and a workgroup
+// (4 waves) a 32 x 16 tile: twice the waves and workgroups, each with about half the instruction chain, 14-23 KB of LDS and
+// 60-88 VGPRs (five workgroups per compute unit for 4 channels, eight for 1 and 3).
 //   * the two DPP rows that share a face in the loop (a "pair of rows": rows 0, 1 and rows 2, 3) are stacked vertically:
 //     an 8 x 8 block walks its distinct faces together -- 3.9 iterations per wave at K3 where the 16 x 8 halves of the
 //     4-pixel kernel need 5.6 (before ring cells), each with half the packed multiply-adds;
-//   * the price: 1.35 x the (block, face) pairs, i.e. float atomics (52.6 k against 38.8 k row groups x 3 vertices at K3).
-// Channel counts 1, 3, 4 (the image's, a compile-time constant); other counts keep grad_kernel's channel passes.
-// Variable names in the per-pixel arithmetic follow the CUDA source.
+//   * the price: 1.35 x the (block, face) pairs, i.e. float atomics (52.6 k against 38.8 k row groups x 3 vertices at K3),
+//     7.6 % more vector and 43 % more scalar instructions summed over the waves.
+// What it was built for -- the 1024 x 1024 x 4-channel headline -- it does NOT speed up (25.3 against 25.7 us; with the op's
+// dense output rows +0.7 us on the step): 62 % of its waves still start in one round and wait 3.6 us for their loads, the
+// rest run at three waves per SIMD, and the kernel is bound by the instructions it issues (DESIGN.md 4.1a,
+// profiles/EXPERIMENTS.md "Round 5": per-wave trace, counters, the all-resident and the persistent two-tile variants).
+// It is the library's choice where it measured faster: 3-channel images of every size above 256 tiles (K3-3ch 23.1 -> 22.2,
+// K5-3ch 66.5 -> 62.2 us: the image deferred shading differentiates) and frames whose 4-pixel grid leaves compute units
+// short of workgroups (257-1023 tiles; K3-768: 24.0 -> 20.8 us).  Channel counts 1, 3, 4 (the image's, a compile-time
+// constant); other counts keep grad_kernel's channel passes.  Variable names in the per-pixel arithmetic follow the CUDA source.
 #include "dirt_device.h"
 #include "dirt_launch.h"
 #include "dirt_reduce.h"
