@@ -217,3 +217,16 @@ def test_no_kernel_uses_scratch_memory_and_the_big_kernels_keep_their_occupancy(
     for c in (1, 3):
         v = res['void dirt::grad_kernel_px2<%d, false>' % c]
         assert v['vgpr'] <= 64 and v['lds'] <= 20480, (c, v)
+
+
+def test_graphed_step_refuses_what_it_cannot_bind():
+    """dirt_amd.GraphedStep binds float32, contiguous GPU tensors in place (they become the captured graph's inputs) and needs
+    exactly one of loss_fn / grad_pixels: anything else is refused before any device work, as the ops refuse CPU tensors."""
+    import dirt_amd
+    bg, v, vc = torch.zeros(1, 8, 8, 3), torch.zeros(1, 4, 4), torch.zeros(1, 4, 3)
+    f = torch.zeros(1, 2, 3, dtype=torch.int32)
+    with pytest.raises(ValueError, match='GPU tensors'):
+        dirt_amd.GraphedStep(bg, v, vc, f, loss_fn=lambda p: p.sum())
+    assert callable(dirt_amd.backward)
+    with pytest.raises(RuntimeError, match='no CPU fallback|MI355X'):
+        dirt_amd.rasterise_batch(bg, v, vc, f)
