@@ -26,6 +26,7 @@ FLAG_GRAD_PAIRS = 0x2000   # ... or pairs of blocks share a face (default otherw
 FLAG_GRAD_SMALL = 0x4000   # ... or the one-pixel-per-lane kernel on 16x16 tiles (default for small frames with 1, 3 or 4 channels)
 FLAG_GRAD_PX2 = 0x8000    # ... or the two-pixels-per-lane kernel on 32x16 tiles (1, 3, 4 channels)
 FLAG_GRAD_PX4 = 0x10000   # ... or the four-pixels-per-lane kernel where the library would choose px2
+FLAG_GRAD_STREAM = 0x20000  # ... or the streaming kernel (4 channels, whole 32x32 tiles; LDS-DMA loads under the compute)
 TEX_CLAMP = 1
 TEX_NEAREST = 2
 

@@ -9,7 +9,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libdirt_hip.so')
-SOURCES = ['dirt_capi.hip', 'dirt_raster.hip', 'dirt_grad.hip', 'dirt_grad_small.hip', 'dirt_grad_px2.hip', 'dirt_texture.hip']
+SOURCES = ['dirt_capi.hip', 'dirt_raster.hip', 'dirt_grad.hip', 'dirt_grad_small.hip', 'dirt_grad_px2.hip', 'dirt_grad_stream.hip', 'dirt_texture.hip']
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'dirt_hip.h')]
 
 # -ffp-contract=off: the numeric specification is a sequence of IEEE basic operations
@@ -51,7 +51,7 @@ def needs_build(extra_flags=()):
 # per-source flags.  dirt_grad.hip: the SLP vectoriser turns two of the four per-pixel barycentric triples into
 # <2 x float> + float stores to a stack slot that is never promoted back to registers (scratch memory + a 3 KB LDS
 # "promoted alloca" in the 1- and 3-channel instantiations); its packed arithmetic is written by hand anyway.
-PER_SOURCE_FLAGS = {'dirt_grad.hip': ['-fno-slp-vectorize'], 'dirt_grad_px2.hip': ['-fno-slp-vectorize']}
+PER_SOURCE_FLAGS = {'dirt_grad.hip': ['-fno-slp-vectorize'], 'dirt_grad_px2.hip': ['-fno-slp-vectorize'], 'dirt_grad_stream.hip': ['-fno-slp-vectorize']}
 OBJ_DIR = os.path.join(_HERE, 'csrc', '.obj')
 
 

@@ -1034,6 +1034,17 @@ hipError_t launch_grad(const GradParams& p_in, hipStream_t stream)
         if (small) return launch_grad_small(p, stream);
     }
     {
+        // The streaming kernel (dirt_grad_stream.hip, round 6): the 4-pixel kernel's decomposition and face loop with wave-private
+        // tiles filled by LDS-DMA, slice 1's loads in flight under slice 0's compute.  4 channels, whole 32 x 32 tiles.
+        // Measured (round 6, profiles/EXPERIMENTS.md): parity-green, and SLOWER than the 4-pixel kernel at every size tried (K3 30.3
+        // against 27.1 us raw, K3-2048 68.8 / 64.7, eight scenes per launch 153 / 152): VMEM issue blocks the wave while the
+        // memory pipeline is backed up, so slice 1's requests do not travel under slice 0's compute.  Opt-in only.
+        bool streamk = false;
+        if (p.flags & DIRT_FLAG_GRAD_STREAM) streamk = grad_stream_eligible(p);
+        if (p.flags & (DIRT_FLAG_GRAD_ROWS | DIRT_FLAG_GRAD_PAIRS | DIRT_FLAG_GRAD_PX4 | DIRT_FLAG_GRAD_PX2 | DIRT_FLAG_GRAD_SMALL)) streamk = false;
+        if (streamk) return launch_grad_stream(p, stream);
+    }
+    {
         // Two pixels per lane (dirt_grad_px2.hip: 32 x 16 tiles, twice the waves at half the chain each, 5-7 workgroups per
         // compute unit).  Measured on MI355X (round 5, gradient kernel in us, HIP events, 10 000 faces, dense outputs):
         //                          32x32 tiles    px2     4-pixel kernel

@@ -105,5 +105,7 @@ hipError_t launch_raster(const RasterParams& p, int B, bool visibility_only, hip
 hipError_t launch_grad(const GradParams& p, hipStream_t stream);
 hipError_t launch_grad_small(const GradParams& p, hipStream_t stream);  // dirt_grad_small.hip; p as filled by launch_grad
 hipError_t launch_grad_px2(const GradParams& p, hipStream_t stream);    // dirt_grad_px2.hip (two pixels per lane, 32 x 16 tiles); p as filled by launch_grad
+bool grad_stream_eligible(const GradParams& p);                         // dirt_grad_stream.hip (4 channels, whole 32 x 32 tiles: loads streamed by LDS-DMA under the compute)
+hipError_t launch_grad_stream(const GradParams& p, hipStream_t stream); // ... p as filled by launch_grad
 
 }  // namespace dirt

@@ -93,6 +93,10 @@ extern "C" {
                                         where it measured faster).  Same results to summation order */
 #define DIRT_FLAG_GRAD_PX4 0x10000u  /* ... or the four-pixels-per-lane kernel (rows or pairs by the library's own rule) where
                                         the library would choose the two-pixels-per-lane one */
+#define DIRT_FLAG_GRAD_STREAM 0x20000u /* ... or the streaming four-pixels-per-lane kernel (4 channels, W and H multiples of 32, no
+                                        debug_thingy: wave-private tiles filled by LDS-DMA while the previous slice is worked on;
+                                        never the library's own choice -- it measured slower, profiles/EXPERIMENTS.md round 6);
+                                        ignored where it does not apply.  Same results to summation order */
 #define DIRT_FLAG_SHARED_FACES 0x800u /* `faces` is one [F,3] topology shared by all B scenes instead of [B,F,3] (the
                                         TODO of csrc/rasterise_egl.cpp:314).  Same flag on the
                                         forward, visibility and backward calls of one scene batch. */
