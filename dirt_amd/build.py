@@ -9,7 +9,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libdirt_hip.so')
-SOURCES = ['dirt_capi.hip', 'dirt_raster.hip', 'dirt_grad.hip', 'dirt_grad_small.hip', 'dirt_grad_px2.hip', 'dirt_grad_stream.hip', 'dirt_texture.hip']
+SOURCES = ['dirt_capi.hip', 'dirt_raster.hip', 'dirt_forward.hip', 'dirt_grad.hip', 'dirt_grad_small.hip', 'dirt_grad_px2.hip', 'dirt_grad_stream.hip', 'dirt_texture.hip']
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'dirt_hip.h')]
 
 # -ffp-contract=off: the numeric specification is a sequence of IEEE basic operations

@@ -12,6 +12,7 @@
 #include <vector>
 #include "../../include/dirt_hip.h"
 #include "dirt_launch.h"
+#include "dirt_raster_common.h"
 
 namespace {
 
@@ -139,7 +140,7 @@ bool armed_take_acc(const void* ws)
 }
 
 struct Workspace {
-    size_t recs_off, boxes_off, cells_off, entries_off, state_a_off, state_b_off, gv_off, gvc_off, total;
+    size_t recs_off, boxes_off, cells_off, entries_off, lrecs_off, crecs_off, state_a_off, state_b_off, gv_off, gvc_off, total;
     int acc_stride;     // the two gradient accumulators share rows of this many floats
 };
 
@@ -154,8 +155,12 @@ Workspace carve(int B, int V, int F, int H, int W, int C)
     w.boxes_off = off;   off = align_up(off + (size_t)B * F * sizeof(dirt::FaceBox), 256);
     int nchunk, chunk_faces;
     dirt::chunking(F, nchunk, chunk_faces);
-    w.cells_off = off;   off = align_up(off + (size_t)B * nchunk * (dirt::MAX_BINS + 1) * sizeof(dirt::BinCell), 256);
+    const bool masked = dirt::directory_is_masked(chunk_faces);
+    w.cells_off = off;   off = align_up(off + (size_t)B * nchunk * ((masked ? dirt::MAX_BINS_MASKED : dirt::MAX_BINS) + 1) * sizeof(dirt::BinCell), 256);
     w.entries_off = off; off = align_up(off + (size_t)B * nchunk * 5 * (size_t)chunk_faces * sizeof(dirt::BinEntry), 256);
+    // (masked directory, setup_kernel_v2: per face its face-local coverage record and its three vertex colours as float4s)
+    w.lrecs_off = off;   off = align_up(off + (masked ? (size_t)B * F * sizeof(dirt::TileRec) : 0), 256);
+    w.crecs_off = off;   off = align_up(off + (masked ? (size_t)B * F * 3 * sizeof(float4) : 0), 256);
     w.state_a_off = off; off = align_up(off + (size_t)B * H * W * sizeof(float2), 256);
     w.state_b_off = off; off = align_up(off + (size_t)B * H * W * sizeof(float2), 256);
     // gradient accumulators of the backward pass, pre-cleared by a KEEP_STATE forward (dirt_state_grad_buffers):
@@ -172,6 +177,8 @@ struct Carved {
     dirt::FaceBox* boxes;
     dirt::BinCell* cells;
     dirt::BinEntry* entries;
+    dirt::TileRec* lrecs;
+    float4* crecs;
     float2* state_a;
     float2* state_b;
     float* gv;
@@ -230,6 +237,8 @@ Carved carved(void* workspace, const Workspace& w)
     c.boxes = reinterpret_cast<dirt::FaceBox*>(ws + w.boxes_off);
     c.cells = reinterpret_cast<dirt::BinCell*>(ws + w.cells_off);
     c.entries = reinterpret_cast<dirt::BinEntry*>(ws + w.entries_off);
+    c.lrecs = reinterpret_cast<dirt::TileRec*>(ws + w.lrecs_off);
+    c.crecs = reinterpret_cast<float4*>(ws + w.crecs_off);
     c.state_a = reinterpret_cast<float2*>(ws + w.state_a_off);
     c.state_b = reinterpret_cast<float2*>(ws + w.state_b_off);
     c.gv = reinterpret_cast<float*>(ws + w.gv_off);
@@ -238,7 +247,7 @@ Carved carved(void* workspace, const Workspace& w)
 }
 
 dirt::GeomParams geom_params(const Carved& c, const float* vertices, const int32_t* faces, int B, int V, int F, int H,
-                             int W, unsigned flags)
+                             int W, unsigned flags, const float* vertex_colors = nullptr, int C = 0)
 {
     dirt::GeomParams g;
     g.shared_faces = (flags & DIRT_FLAG_SHARED_FACES) ? 1 : 0;
@@ -247,7 +256,14 @@ dirt::GeomParams geom_params(const Carved& c, const float* vertices, const int32
     dirt::chunking(F, g.nchunk, g.chunk_faces);
     g.masked = dirt::directory_is_masked(g.chunk_faces) ? 1 : 0;
     g.B = B; g.V = V; g.F = F; g.H = H; g.W = W;
-    g.grid = dirt::make_bin_grid(H, W);
+    g.grid = dirt::make_bin_grid(H, W, g.nchunk, g.masked != 0);
+    g.v2_only = 0;
+    g.lrecs = g.masked ? c.lrecs : nullptr;
+    // the faces' vertex colours ride along for the forward pass of 1 / 3 / 4-channel images (raster_kernel_v2)
+    const bool colours = g.masked && vertex_colors != nullptr && V > 0 && (C == 1 || C == 3 || C == 4);
+    g.crecs = colours ? c.crecs : nullptr;
+    g.vertex_colors = colours ? vertex_colors : nullptr;
+    g.C = C;
     return g;
 }
 
@@ -256,6 +272,7 @@ dirt::RasterParams raster_params(const Carved& c, const dirt::GeomParams& g, int
     dirt::RasterParams p;
     p.flags = flags;
     p.recs = c.recs; p.cells = c.cells; p.entries = c.entries; p.nchunk = g.nchunk; p.chunk_faces = g.chunk_faces; p.masked = g.masked;
+    p.lrecs = g.lrecs; p.crecs = g.crecs;
     p.background = nullptr; p.vertex_colors = nullptr; p.pixels = nullptr; p.vis = nullptr; p.state_a = nullptr; p.state_b = nullptr;
     p.V = g.V; p.F = g.F; p.H = g.H; p.W = g.W; p.C = C;
     p.grid = g.grid; p.tiles_x = 0; p.tiles_y = 0;
@@ -295,13 +312,14 @@ static int forward_impl(const char* who, const float* background, const float* v
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const Carved c = carved(workspace, w);
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
-    const dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
+    dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags, vertex_colors, C);
+    dirt::RasterParams p = raster_params(c, g, C, flags);
+    p.background = background; p.vertex_colors = vertex_colors; p.pixels = pixels;
+    g.v2_only = dirt::raster_v2_applies(p, B, false) ? 1 : 0;   // (set-up then skips what only dirt_raster.hip's kernels read)
     {
         Scope sc(prof, SLOT_GEOMETRY, stream);
         HIP_TRY(who, dirt::launch_geometry(g, stream));
     }
-    dirt::RasterParams p = raster_params(c, g, C, flags);
-    p.background = background; p.vertex_colors = vertex_colors; p.pixels = pixels;
     const bool dense = grad_vertices != nullptr && grad_vertex_colors != nullptr && V > 0;
     if (flags & DIRT_FLAG_KEEP_STATE) {
         p.state_a = c.state_a; p.state_b = c.state_b;
@@ -362,13 +380,14 @@ int dirt_rasterise_visibility(const float* vertices, const int32_t* faces, int32
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const Carved c = carved(workspace, w);
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
-    const dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
+    dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
+    dirt::RasterParams p = raster_params(c, g, 1, flags);
+    p.vis = face_id;
+    g.v2_only = dirt::raster_v2_applies(p, B, true) ? 1 : 0;
     {
         Scope sc(prof, SLOT_GEOMETRY, stream);
         HIP_TRY(who, dirt::launch_geometry(g, stream));
     }
-    dirt::RasterParams p = raster_params(c, g, 1, flags);
-    p.vis = face_id;
     {
         Scope sc(prof, SLOT_RASTER_VIS, stream);
         HIP_TRY(who, dirt::launch_raster(p, B, true, stream));
@@ -424,12 +443,13 @@ int dirt_rasterise_backward(const float* vertices, const int32_t* faces, const f
         }
     } else {
         armed_set(workspace, nullptr, nullptr, false);   // the state is rebuilt below; its accumulators are not cleared
-        const dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
+        dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
+        dirt::RasterParams rp = raster_params(c, g, C, flags);
+        g.v2_only = dirt::raster_v2_applies(rp, B, true) ? 1 : 0;
         {
             Scope sc(prof, SLOT_GEOMETRY, stream);
             HIP_TRY(who, dirt::launch_geometry(g, stream));
         }
-        dirt::RasterParams rp = raster_params(c, g, C, flags);
         rp.state_a = c.state_a; rp.state_b = c.state_b;
         rp.zero_b = grad_vertices;      rp.zero_b_bytes = sizeof(float) * (size_t)B * V * 4;
         rp.zero_c = grad_vertex_colors; rp.zero_c_bytes = sizeof(float) * (size_t)B * V * C;

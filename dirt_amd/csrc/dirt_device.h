@@ -22,16 +22,19 @@ namespace dirt {
 // Sign folding: for an edge whose on-edge samples are EXCLUDED by the tie rule the three
 // coefficients are stored negated (F_k = -E_k).  The coverage test then is a single `F_k >= 0`
 // compare per edge, xor-ed with the edge's `excl` flag.
+// (Round 6: what the SHADING pass reads -- coefficients, 1/|det|, flags, vertex indices -- is the first 96 bytes, six 16-byte
+// pieces that raster_kernel_v2 copies into LDS by LDS-DMA while its coverage loop runs; the depth plane follows.)
 struct alignas(128) FaceRec {
     double coef[9];   //   0: (a,b,c) of edges 0,1,2, sign-folded
-    double zp[3];     //  72: depth plane scaled to the 24-bit range: q = fma(zp[0], px, fma(zp[1], py, zp[2]))
-    uint32_t flags;   //  96: bit k = edge k folded (exclusive); bit 31 = valid
-    uint32_t pad0;    // 100
-    double inv_det;   // 104: 1/|det|
-    int32_t vid[3];   // 112: vertex indices of the face
+    double inv_det;   //  72: 1/|det|
+    uint32_t flags;   //  80: bit k = edge k folded (exclusive); bit 31 = valid
+    int32_t vid[3];   //  84: vertex indices of the face
+    double zp[3];     //  96: depth plane scaled to the 24-bit range: q = fma(zp[0], px, fma(zp[1], py, zp[2]))
+    uint32_t pad0;    // 120
     uint32_t pad1;    // 124
 };
 static_assert(sizeof(FaceRec) == 128, "FaceRec must be 128 bytes");
+constexpr int FACE_SHADE_BYTES = 96;   // the head of a FaceRec the shading pass reads
 
 constexpr uint32_t FACE_VALID = 0x80000000u;
 

@@ -1,0 +1,516 @@
+// dirt_forward.hip -- the forward pass in TWO dependent trips per tile (gfx950, round 6): set-up that leaves tile-ready,
+// face-local coverage records behind, and a raster kernel that copies them into LDS by LDS-DMA.
+//
+// Replaces (as dirt_raster.hip does, whose kernels remain for meshes of more than 16 384 faces, 16 x 16 tiles and channel
+// counts other than 1, 3, 4): the GL vertex pipeline + upload_vertices (csrc/rasterise_grad_egl.cu:12-34), the per-scene
+// { glViewport, glScissor, glClear(DEPTH), glDrawElementsBaseVertex } (csrc/rasterise_egl.cpp:362-380) and
+// upload_background / download_pixels (csrc/rasterise_egl.cu:10-38,65-91).
+//
+// Rounds 1-5: a raster tile walked directory -> entries {box, face} -> set-up records -> vertex colours: FOUR dependent memory
+// round trips and three workgroup barriers before the first sample was tested -- 7.3 of the kernel's 18.7 us at K3, the same
+// whether 576 or 1024 tiles are rendered (profiles/EXPERIMENTS.md, round 4 knock-outs).  Here:
+//   * setup_kernel_v2 (one wave per chunk of 64 faces, one face per lane) writes per face, besides the 128-byte set-up
+//     record, its FACE-LOCAL coverage record (make_local_rec: float32 edge functions about the top-left pixel of the face's own
+//     box + certified bound + f64 depth plane + box: the 80 bytes the coverage loop reads, valid for every tile) and its three
+//     vertex colours as float4s; bins are 32-pixel squares -- the raster tiles themselves up to 1024 x 1024 -- so a bin's
+//     faces ARE a tile's candidates and no box list is consulted; a face may touch up to 16 bins before it goes to the
+//     "big" list.  For meshes whose faces are (3f, 3f+1, 3f+2) -- split vertices, what dirt/lighting.py's
+//     split_vertices_by_face produces -- the vertices and colours are requested together with the indices (one round trip).
+//   * raster_kernel_v2: trip 1 reads the tile's row of the bin x chunk mask directory; the set bits are the candidates; trip 2
+//     is ONE round of LDS-DMA: the candidates' 80-byte coverage records straight into LDS (lane <-> 16-byte piece, linear),
+//     then -- issued behind them, landing while the coverage loop runs -- the 96-byte heads of their set-up records and their
+//     colours for the shading pass.  Coverage, depth and shading arithmetic are dirt_raster.hip's (dirt_raster_common.h).
+#include "dirt_device.h"
+#include "dirt_launch.h"
+#include "dirt_raster_common.h"
+#include "../../include/dirt_hip.h"
+
+namespace dirt {
+
+#ifdef DIRT_TRACE
+// Per-wave phase timestamps (s_memtime) for tools/trace_forward.py; compiled only into the tracing build of the library.
+__device__ long long* g_trace_fwd_setup = nullptr;
+__device__ long long* g_trace_fwd_raster = nullptr;
+extern "C" void dirt_debug_set_trace_forward(void* ps, void* pr)
+{
+    long long* q = reinterpret_cast<long long*>(ps);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_fwd_setup), &q, sizeof(q));
+    q = reinterpret_cast<long long*>(pr);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_fwd_raster), &q, sizeof(q));
+}
+#define FMARK() do { if (tr_n < 12) { long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tr_t[tr_n++] = t_; } } while (0)
+#define FTRACE_DECL() long long tr_t[12]; int tr_n = 0; const long long tr_wall0 = wall_clock64()
+#else
+#define FMARK() do {} while (0)
+#define FTRACE_DECL() do {} while (0)
+#endif
+
+namespace {
+
+constexpr int MAX_FACE_BINS = 16;   // bins a face may touch before it goes to the "big" pseudo-bin (read by every tile)
+
+// One LDS-DMA wave-instruction: lane l's 16 bytes at base + voff land at LDS byte address lds_addr + 16 l (lanes switched off
+// by the surrounding branch write nothing).  M0 holds the destination; saved and restored around the statement.  Not counted
+// by the compiler: the kernel waits with s_waitcnt vmcnt(0) itself.
+__device__ __forceinline__ void glds16(const void* base, uint32_t voff, uint32_t lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+
+struct Float3v { float x, y, z; };   // three channels of a vertex colour: one 12-byte load
+
+template <class T>
+__device__ __forceinline__ uint32_t lds_address(T* p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)p;
+}
+
+}  // namespace
+
+// ---- set-up ----------------------------------------------------------------------------------------------------------
+// CK: the channel count whose vertex colours ride along (1, 3, 4), or 0: none (the visibility / stateless backward passes).
+template <int CK>
+__global__ __launch_bounds__(64) void setup_kernel_v2(GeomParams g)
+{
+    __shared__ unsigned long long s_mask[MAX_BINS_MASKED + 1];    // [grid.big] = big faces
+    const int ib = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
+    FTRACE_DECL();
+    FMARK();  // 0 start
+    const int nbins = g.grid.bins_x * g.grid.bins_y, big = g.grid.big;
+    BinCell* __restrict__ row = g.cells + ((size_t)ib * g.nchunk + chunk) * (size_t)(big + 1);   // chunk-major: this chunk's cells are contiguous
+    const int f = chunk * 64 + lane;
+    const bool have = f < g.F && g.V > 0;
+    if (g.F == 0 || g.V <= 0) {   // (uniform) nothing to set up: an all-zero row is what the raster kernel reads
+        for (int i = lane; i <= big; i += 64) if (i < nbins || i == big) row[i] = BinCell{0u, 0u};
+        return;
+    }
+    const int fs = have ? f : 0;                                   // (lanes past the last face: face 0, nothing stored)
+    const size_t n = (size_t)ib * g.F + fs;
+    const float* __restrict__ verts = g.vertices + (size_t)ib * g.V * 4;
+    const float* __restrict__ cols = CK ? g.vertex_colors + (size_t)ib * g.V * CK : nullptr;
+    auto fetch_colour = [&](int vid) {
+        const float* __restrict__ cp = cols + (size_t)vid * CK;
+        if constexpr (CK == 4) return *reinterpret_cast<const float4*>(cp);
+        else if constexpr (CK == 3) { const Float3v q = *reinterpret_cast<const Float3v*>(cp); return make_float4(q.x, q.y, q.z, 0.f); }
+        else return make_float4(cp[0], 0.f, 0.f, 0.f);
+    };
+    // The face's indices and -- speculatively, for the identity triple (3f, 3f+1, 3f+2) of split-vertex meshes -- its vertices
+    // and colours are requested TOGETHER, branch-free (clamped addresses: a load inside a divergent branch is waited for
+    // inside it): one memory round trip instead of two for such meshes; any other mesh pays the unused requests and takes the
+    // second trip below.
+    int32_t idx[3];
+    float4 vv[3], cv[3];
+    {
+        const int32_t* __restrict__ fp = g.faces + (g.shared_faces ? (size_t)fs : n) * 3;
+        idx[0] = fp[0]; idx[1] = fp[1]; idx[2] = fp[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int sv = min(3 * fs + k, g.V - 1);
+        vv[k] = *reinterpret_cast<const float4*>(verts + (size_t)sv * 4);
+        cv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (CK != 0) cv[k] = fetch_colour(sv);
+    }
+    for (int i = lane; i < nbins; i += 64) s_mask[i] = 0ull;
+    if (lane == 0) s_mask[big] = 0ull;
+    FMARK();  // 1 requests issued, masks cleared
+    const bool identity = 3 * fs + 2 < g.V && idx[0] == 3 * fs && idx[1] == 3 * fs + 1 && idx[2] == 3 * fs + 2;
+    if (__builtin_amdgcn_ballot_w64(have && !identity) != 0ull) {   // (wave-uniform) some face of the chunk is not the identity triple
+        int32_t ci[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ci[k] = identity ? 3 * fs + k : ((uint32_t)idx[k] < (uint32_t)g.V ? idx[k] : 0);   // a bad index reads vertex 0 (the face is dropped below)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            vv[k] = *reinterpret_cast<const float4*>(verts + (size_t)ci[k] * 4);
+            if constexpr (CK != 0) cv[k] = fetch_colour(ci[k]);
+        }
+    }
+    __syncthreads();
+    FMARK();  // 2 indices (+ vertices of the identity triple, or the second trip) there
+    if (have) {
+        FaceRec rec;
+        FaceBox box;
+        if (setup_face_from(vv, idx, g.V, g.H, g.W, rec, box)) {
+            if (g.v2_only) {   // raster_kernel_v2 reads the record's 96-byte head only (the depth plane is in the coverage record)
+                const uint4* src = reinterpret_cast<const uint4*>(&rec);
+                uint4* dst = reinterpret_cast<uint4*>(&g.recs[n]);
+#pragma unroll
+                for (int i = 0; i < FACE_SHADE_BYTES / 16; ++i) dst[i] = src[i];
+            } else {
+                g.recs[n] = rec;
+            }
+            TileRec lr;
+            make_local_rec(rec, f, box, g.H, (float)g.W, (float)g.H, &lr);
+            g.lrecs[n] = lr;
+            if constexpr (CK != 0) { g.crecs[3 * n] = cv[0]; g.crecs[3 * n + 1] = cv[1]; g.crecs[3 * n + 2] = cv[2]; }
+            const unsigned long long bit = 1ull << lane;
+            const int bx0 = box.i_min >> g.grid.shift, bx1 = box.i_max >> g.grid.shift;
+            const int by0 = box.r_min >> g.grid.shift, by1 = box.r_max >> g.grid.shift;
+            if ((bx1 - bx0 + 1) * (by1 - by0 + 1) <= MAX_FACE_BINS) {
+                for (int by = by0; by <= by1; ++by)
+                    for (int bx = bx0; bx <= bx1; ++bx) atomicOr(&s_mask[by * g.grid.bins_x + bx], bit);
+            } else {
+                atomicOr(&s_mask[big], bit);
+            }
+            if (!g.v2_only) {
+                // (the {box, face} entry at its fixed slot: what dirt_raster.hip's kernels -- 16 x 16 tiles, other channel counts --
+                // read behind the same masks)
+                BinEntry e;
+                e.box = box; e.face = f; e.pad = 0;
+                g.entries[((size_t)ib * g.nchunk + chunk) * (5 * (size_t)g.chunk_faces) + lane] = e;
+            }
+        } else {
+            g.recs[n].flags = 0;   // (no bit anywhere: its records are never read)
+        }
+    }
+    FMARK();  // 3 set-up, record stores, masks
+    __syncthreads();
+    FMARK();  // 4
+    for (int i = lane; i < nbins; i += 64) {
+        const unsigned long long m = s_mask[i];
+        row[i] = BinCell{(uint32_t)m, (uint32_t)(m >> 32)};
+    }
+    if (lane == 63) {
+        const unsigned long long m = s_mask[big];
+        row[big] = BinCell{(uint32_t)m, (uint32_t)(m >> 32)};
+    }
+    FMARK();  // 5 directory stores issued
+#ifdef DIRT_TRACE
+    if (lane == 0 && g_trace_fwd_setup) {
+        long long* o = g_trace_fwd_setup + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+        for (int i = 0; i < 12; ++i) o[i] = i < tr_n ? tr_t[i] : 0;
+        o[12] = tr_wall0; o[13] = (long long)wall_clock64() - tr_wall0;
+    }
+#endif
+}
+
+hipError_t launch_geometry_v2(const GeomParams& g, hipStream_t stream)
+{
+    const dim3 grid((unsigned)g.nchunk, (unsigned)g.B);
+    const int ck = g.crecs ? g.C : 0;
+    if (ck == 4) hipLaunchKernelGGL(setup_kernel_v2<4>, grid, dim3(64), 0, stream, g);
+    else if (ck == 3) hipLaunchKernelGGL(setup_kernel_v2<3>, grid, dim3(64), 0, stream, g);
+    else if (ck == 1) hipLaunchKernelGGL(setup_kernel_v2<1>, grid, dim3(64), 0, stream, g);
+    else hipLaunchKernelGGL(setup_kernel_v2<0>, grid, dim3(64), 0, stream, g);
+    return hipGetLastError();
+}
+
+// ---- raster ----------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int V2_CAP = 96;       // candidates per round whose records live in LDS
+
+// What the shading pass reads of a candidate, as LDS-DMA leaves it: the head of its FaceRec, then (MODE 0) its colours.
+template <bool COLOURS>
+struct alignas(16) ShadeSlot {
+    double coef[9];
+    double inv_det;
+    uint32_t flags;
+    int32_t vid[3];
+    float4 col[COLOURS ? 3 : 0];
+};
+static_assert(sizeof(ShadeSlot<true>) == 144 && sizeof(ShadeSlot<false>) == 96, "16-byte pieces: 6 of the record, 3 colours");
+
+}  // namespace
+
+// raster_kernel_v2<MODE, CSPEC>: MODE 0 renders CSPEC = 1, 3, 4 channels (pixels, and the backward pass's state when
+// p.state_a); MODE 1 is the visibility pass (p.vis and / or the state; no colours).  32 x 32-pixel tiles, four waves, each
+// owning a 16 x 16 region = 2 x 2 blocks of 8 x 8 pixels (one pixel of every block per lane), from the coverage loop to the
+// stores: dirt_raster.hip's decomposition.
+template <int MODE, int CSPEC>
+__global__ __launch_bounds__(RTHREADS, 4) void raster_kernel_v2(RasterParams p)
+{
+    constexpr int NB = 2, TILE = 32, PPL = 4;
+    constexpr bool COLOURS = MODE == 0;
+    constexpr int SPARTS = COLOURS ? 9 : 6;
+    using Slot = ShadeSlot<COLOURS>;
+    __shared__ __align__(16) TileRec s_rec[V2_CAP];
+    __shared__ __align__(16) Slot s_shade[V2_CAP];
+    __shared__ int32_t s_face[V2_CAP];
+    __shared__ uint32_t s_count;
+
+    FTRACE_DECL();
+    FMARK();  // 0 start
+#ifdef DIRT_TRACE
+    int tr_cand = 0;
+#endif
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ib = blockIdx.y;
+    const int tile = xcd_tile(blockIdx.x, p.tiles_x * p.tiles_y);
+    int tile_col, tile_row;
+    tile_xy(tile, p.tiles_x, p.tiles_x_magic, tile_col, tile_row);
+    const int tx0 = tile_col * TILE, tr0 = tile_row * TILE;
+    constexpr int C = CSPEC;
+
+    const FaceRec* __restrict__ recs = p.recs + (size_t)ib * p.F;
+    const TileRec* __restrict__ lrecs = p.lrecs + (size_t)ib * p.F;
+    const float4* __restrict__ crecs = COLOURS ? p.crecs + (size_t)ib * p.F * 3 : nullptr;
+    // ---- trip 1: this tile's cell of every chunk -- the mask of the chunk's faces that touch the tile's bin -- and the
+    //      chunk's mask of "big" faces.  One chunk per thread (<= 256 chunks of 64 faces). ----
+    const int bin = (tr0 >> p.grid.shift) * p.grid.bins_x + (tx0 >> p.grid.shift);
+    const BinCell* __restrict__ cells = p.cells + (size_t)ib * p.nchunk * (size_t)(p.grid.big + 1);
+    unsigned long long m_bin = 0ull, m_big = 0ull;
+    if (tid < p.nchunk) {
+        const BinCell* __restrict__ rowc = cells + (size_t)tid * p.grid.cell_chunk_stride;   // (chunk-major: cell_bin_stride is 1)
+        const BinCell a = rowc[bin], b = rowc[p.grid.big];
+        m_bin = ((unsigned long long)a.count << 32) | a.start;
+        m_big = ((unsigned long long)b.count << 32) | b.start;
+    }
+
+    // this wave's region (blocks 2 wx .., 2 wy .. of the tile) and this lane's 2 x 2 pixels
+    const int wx = wave & 1, wy = wave >> 1;
+    const int x0 = tx0 + wx * 16 + (lane & 7);
+    const int r0 = tr0 + wy * 16 + (lane >> 3);
+    double px[NB], py[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        px[k] = (double)(x0 + 8 * k) + 0.5;
+        py[k] = (double)(p.H - 1 - (r0 + 8 * k)) + 0.5;
+    }
+    unsigned long long best[PPL];   // (z24 << 32 | face) of the front-most fragment so far
+    int cbest[PPL];                 // the winner's slot (its shading data is in LDS when < V2_CAP and lds_records)
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) { best[k] = (unsigned long long)Z24_CLEAR << 32; cbest[k] = V2_CAP; }  // a tie with the cleared depth never wins
+    bool lds_records = true;   // false once a second round has reused the slots (dense meshes): shading data comes from memory then
+
+    // side job: this workgroup's share of the buffers the launch clears (the backward pass's gradient accumulators)
+    if ((p.zero_b_bytes | p.zero_c_bytes) != 0) {
+        const unsigned gwg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (p.zero_b_bytes) zero_share(p.zero_b, p.zero_b_bytes, p.zero_b_per, gwg, tid);
+        if (p.zero_c_bytes) zero_share(p.zero_c, p.zero_c_bytes, p.zero_c_per, gwg, tid);
+    }
+    const uint32_t lds_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(&s_rec[0]));
+    const uint32_t lds_shade = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(&s_shade[0]));
+
+    FMARK();  // 1 cells requested, side job issued
+    for (int round = 0;; ++round) {
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        FMARK();  // 2 (round 0)
+        // ---- the candidates: every set bit claims a slot (a wave-wide prefix of the threads' bit counts, ONE LDS atomic per
+        //      wave); bits beyond the round's capacity stay for the next round ----
+        {
+            const uint32_t cnt = (uint32_t)__popcll(m_bin) + (uint32_t)__popcll(m_big);
+            uint32_t incl = cnt;   // inclusive prefix over the 64 lanes: DPP row shifts, then the rows' totals carried across
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112 /* row_shr:2 */, 0xF, 0xF, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114 /* row_shr:4 */, 0xF, 0xF, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118 /* row_shr:8 */, 0xF, 0xF, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t base = 0;
+            if (total != 0u) {   // (wave-uniform)
+                if (lane == 0) base = atomicAdd(&s_count, total);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            }
+            uint32_t slot = base + incl - cnt;
+            const int face0 = tid * 64;
+            while (m_bin != 0ull && slot < (uint32_t)V2_CAP) {
+                s_face[slot++] = face0 + (__ffsll((long long)m_bin) - 1);
+                m_bin &= m_bin - 1ull;
+            }
+            while (m_big != 0ull && slot < (uint32_t)V2_CAP) {
+                s_face[slot++] = face0 + (__ffsll((long long)m_big) - 1);
+                m_big &= m_big - 1ull;
+            }
+        }
+        FMARK();  // 3 cells there, slots claimed
+        __syncthreads();
+        FMARK();  // 4
+        const int n = (int)min(s_count, (uint32_t)V2_CAP);
+        if (round != 0) lds_records = false;
+
+        // ---- trip 2: the candidates' coverage records, 16-byte piece idx = 5 slot + part, lane-linear into s_rec ----
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = tid + RTHREADS * k;
+            if (idx < 5 * n) {
+                const int slot = idx / 5, part = idx - 5 * slot;
+                glds16(lrecs, (uint32_t)s_face[slot] * (uint32_t)sizeof(TileRec) + 16u * (uint32_t)part, lds_rec + 1024u * (uint32_t)(wave + 4 * k));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FMARK();  // 5 coverage records landed
+        __syncthreads();
+        FMARK();  // 6
+        // ---- ... and, landing while the coverage loop runs, what the shading pass reads of them: piece idx = SPARTS slot +
+        //      part: the six pieces of the set-up record's head, then the three colours ----
+        if (round == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = tid + RTHREADS * k;
+                if (idx < SPARTS * n) {
+                    const int slot = idx / SPARTS, part = idx - SPARTS * slot;
+                    const uint32_t face = (uint32_t)s_face[slot];
+                    const uint32_t dst = lds_shade + 1024u * (uint32_t)(wave + 4 * k);
+                    if (part < 6) glds16(recs, face * (uint32_t)sizeof(FaceRec) + 16u * (uint32_t)part, dst);
+                    if (COLOURS && part >= 6) glds16(crecs, face * 48u + 16u * (uint32_t)(part - 6), dst);
+                }
+            }
+        }
+
+        // ---- coverage + depth: every wave visits the candidates whose box touches one of its four blocks ----
+        for (int cb = 0; cb < n; cb += 64) {
+            const int idx = cb + lane;
+            uint32_t mym4 = 0;
+            if (idx < n) {
+                const FaceBox box = s_rec[idx].box;
+                // the wave's blocks (bx, by) the box touches, as bits 2 by + bx
+                const int rx0 = tx0 + 16 * wx, ry0 = tr0 + 16 * wy;
+                const int bx0 = max(box.i_min - rx0, 0) >> 3, bx1 = min(box.i_max - rx0, 15) >> 3;
+                const int by0 = max(box.r_min - ry0, 0) >> 3, by1 = min(box.r_max - ry0, 15) >> 3;
+                if (box.i_max >= rx0 && box.i_min <= rx0 + 15 && box.r_max >= ry0 && box.r_min <= ry0 + 15) {
+                    const uint32_t rowbits = (bx0 == 0 ? 1u : 0u) | (bx1 == 1 ? 2u : 0u);
+                    mym4 = (by0 == 0 ? rowbits : 0u) | (by1 == 1 ? rowbits << 2 : 0u);
+                }
+            }
+            unsigned long long m = __builtin_amdgcn_ballot_w64(mym4 != 0);
+            while (m) {
+                const int k = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const TileRec t = s_rec[cb + k];
+                const uint32_t m4 = (uint32_t)__builtin_amdgcn_readlane((int)mym4, k);
+                // sample offsets from the face's origin (the top-left pixel of its box): exact small integers
+                float dxl[NB], dyl[NB];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    dxl[q] = (float)(x0 + 8 * q - (int)t.box.i_min);
+                    dyl[q] = (float)((int)t.box.r_min - (r0 + 8 * q));
+                }
+                raster_candidate<NB>(t, recs, round == 0 ? cb + k : V2_CAP, m4, dxl, dyl, px, py, best, cbest);
+#ifdef DIRT_TRACE
+                ++tr_cand;
+#endif
+            }
+        }
+        FMARK();  // 7 coverage loop done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the shading data has landed
+        const bool more = (m_bin | m_big) != 0ull;
+        if (!__syncthreads_or(more)) break;
+    }
+    FMARK();  // 8 shading data landed, barrier
+
+    int32_t fbest[PPL];   // the front-most face per pixel, -1: none (nothing was less than the cleared depth)
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) fbest[k] = (uint32_t)(best[k] >> 32) != Z24_CLEAR ? (int32_t)(uint32_t)best[k] : -1;
+
+    // ---- shade ----
+    // this lane's pixels: background where nothing is visible (requested now, used last)
+    bool inside[PPL];
+    size_t pix[PPL];
+    float4 bgv[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        const int x = x0 + 8 * (k % NB), r = r0 + 8 * (k / NB);
+        inside[k] = x < p.W && r < p.H;
+        pix[k] = ((size_t)ib * p.H + min(r, p.H - 1)) * p.W + min(x, p.W - 1);
+        bgv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 0 && inside[k] && fbest[k] < 0) {
+            const float* __restrict__ bg = p.background + pix[k] * C;
+            if (CSPEC == 4) bgv[k] = *reinterpret_cast<const float4*>(bg);
+            else if (CSPEC == 3) bgv[k] = make_float4(bg[0], bg[1], bg[2], 0.f);
+            else bgv[k] = make_float4(bg[0], 0.f, 0.f, 0.f);
+        }
+    }
+    // Per pixel: barycentrics of the winner (csrc/shaders.cpp:52-57,74) from its record in LDS -- or, for candidates of later
+    // rounds, in memory --, the backward pass's state, the interpolated colours, the HWC pixel.
+    const float* __restrict__ cols = COLOURS ? p.vertex_colors + (size_t)ib * p.V * C : nullptr;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        const int32_t f = fbest[k];
+        const bool has = f >= 0;
+        const bool from_lds = has && lds_records && cbest[k] < V2_CAP;
+        const int ci = from_lds ? cbest[k] : 0;   // (lanes without a winner read slot 0; what they compute is not used)
+        double cf[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) cf[i] = s_shade[ci].coef[i];
+        uint32_t flags = s_shade[ci].flags;
+        double inv_det = s_shade[ci].inv_det;
+        float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0, u2 = u0;
+        if constexpr (COLOURS) { u0 = s_shade[ci].col[0]; u1 = s_shade[ci].col[1]; u2 = s_shade[ci].col[2]; }
+        if (__builtin_amdgcn_ballot_w64(has && !from_lds) != 0ull) {
+            if (has && !from_lds) {
+                const FaceRec* __restrict__ rec = recs + f;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) cf[i] = rec->coef[i];
+                flags = rec->flags; inv_det = rec->inv_det;
+                if constexpr (COLOURS) {
+                    const float* __restrict__ c0 = cols + (size_t)rec->vid[0] * C;
+                    const float* __restrict__ c1 = cols + (size_t)rec->vid[1] * C;
+                    const float* __restrict__ c2 = cols + (size_t)rec->vid[2] * C;
+                    if (CSPEC == 4) { u0 = *reinterpret_cast<const float4*>(c0); u1 = *reinterpret_cast<const float4*>(c1); u2 = *reinterpret_cast<const float4*>(c2); }
+                    else if (CSPEC == 3) { u0 = make_float4(c0[0], c0[1], c0[2], 0.f); u1 = make_float4(c1[0], c1[1], c1[2], 0.f); u2 = make_float4(c2[0], c2[1], c2[2], 0.f); }
+                    else { u0 = make_float4(c0[0], 0.f, 0.f, 0.f); u1 = make_float4(c1[0], 0.f, 0.f, 0.f); u2 = make_float4(c2[0], 0.f, 0.f, 0.f); }
+                }
+            }
+        }
+        double Fk[3];
+        edge_eval(cf, (double)(x0 + 8 * (k % NB)) + 0.5, (double)(p.H - 1 - (r0 + 8 * (k / NB))) + 0.5, Fk);
+        float b[3], cw;
+        bary_eval(Fk, flags, inv_det, b, cw);
+        const float b0 = b[0], b1 = b[1], b2 = b[2];
+        if (!inside[k]) continue;
+        // the backward pass's state and the visibility export
+        if (p.vis) p.vis[pix[k]] = f;
+        if (p.state_a) store_state(p, pix[k], has, b0, b1, b2, cw, f);
+        if (MODE != 0) continue;
+        float* __restrict__ out = p.pixels + pix[k] * C;
+        float4 o = bgv[k];   // pixels start as the background: csrc/rasterise_egl.cpp:348-356
+        if (has) {
+            o.x = fmaf(b2, u2.x, fmaf(b1, u1.x, b0 * u0.x));
+            if (CSPEC >= 3) { o.y = fmaf(b2, u2.y, fmaf(b1, u1.y, b0 * u0.y)); o.z = fmaf(b2, u2.z, fmaf(b1, u1.z, b0 * u0.z)); }
+            if (CSPEC == 4) o.w = fmaf(b2, u2.w, fmaf(b1, u1.w, b0 * u0.w));
+        }
+        if (CSPEC == 4) *reinterpret_cast<float4*>(out) = o;
+        else if (CSPEC == 3) { out[0] = o.x; out[1] = o.y; out[2] = o.z; }
+        else out[0] = o.x;
+    }
+    FMARK();  // 9 shaded, stores issued
+#ifdef DIRT_TRACE
+    if (lane == 0 && g_trace_fwd_raster) {
+        long long* o = g_trace_fwd_raster + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16;
+        for (int i = 0; i < 12; ++i) o[i] = i < tr_n ? tr_t[i] : 0;
+        o[12] = tr_wall0; o[13] = (long long)wall_clock64() - tr_wall0; o[14] = blockIdx.x; o[15] = tr_cand;
+    }
+#endif
+}
+
+// Which launches take the two-trip kernel: the masked directory with its face-local records (meshes of up to 16 384 faces),
+// 32 x 32-pixel tiles (the library's choice from 512 such tiles on, or pinned), 1 / 3 / 4 channels or the visibility pass.
+bool raster_v2_applies(const RasterParams& p, int B, bool visibility_only)
+{
+    if (!p.masked || p.lrecs == nullptr) return false;
+    const long long tiles32 = (long long)((p.W + 31) / 32) * ((p.H + 31) / 32) * B;
+    int tile = tiles32 >= 512 ? 32 : 16;
+    if (p.flags & DIRT_FLAG_TILES_LARGE) tile = 32;
+    if (p.flags & DIRT_FLAG_TILES_SMALL) tile = 16;
+    if (tile != 32) return false;
+    if (visibility_only) return true;
+    return (p.C == 1 || p.C == 3 || p.C == 4) && p.crecs != nullptr;
+}
+
+hipError_t launch_raster_v2(const RasterParams& p_in, int B, bool visibility_only, hipStream_t stream)
+{
+    RasterParams p = p_in;
+    p.tiles_x = (p.W + 31) / 32;
+    p.tiles_y = (p.H + 31) / 32;
+    p.tiles_x_magic = tile_magic(p.tiles_x);
+    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)B);
+    {
+        const size_t nwg = (size_t)grid.x * grid.y;
+        p.zero_b_per = (unsigned)((p.zero_b_bytes / 16 + nwg - 1) / nwg);
+        p.zero_c_per = (unsigned)((p.zero_c_bytes / 16 + nwg - 1) / nwg);
+    }
+    if (visibility_only) hipLaunchKernelGGL((raster_kernel_v2<1, 4>), grid, dim3(RTHREADS), 0, stream, p);
+    else if (p.C == 4) hipLaunchKernelGGL((raster_kernel_v2<0, 4>), grid, dim3(RTHREADS), 0, stream, p);
+    else if (p.C == 3) hipLaunchKernelGGL((raster_kernel_v2<0, 3>), grid, dim3(RTHREADS), 0, stream, p);
+    else hipLaunchKernelGGL((raster_kernel_v2<0, 1>), grid, dim3(RTHREADS), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace dirt

@@ -6,11 +6,18 @@
 
 namespace dirt {
 
-constexpr int MAX_BINS = 256;
+struct TileRec;   // dirt_raster_common.h
 
-// Coarse binning grid: square bins of (1 << shift) pixels, shift >= 5, bins_x * bins_y <= MAX_BINS.
+constexpr int MAX_BINS = 256;           // bins of the start / count directory (setup_kernel<NW>: meshes of more than 16 384 faces)
+constexpr int MAX_BINS_MASKED = 1024;   // bins of the masked directory (setup_kernel_v2): 32-pixel bins = raster tiles up to 1024 x 1024
+
+// Coarse binning grid: square bins of (1 << shift) pixels, shift >= 5, bins_x * bins_y <= big (MAX_BINS or MAX_BINS_MASKED);
+// `big`: the row of the directory that holds the "big" pseudo-bin (faces touching too many bins), which every tile reads.
 struct BinGrid {
-    int shift, bins_x, bins_y;
+    int shift, bins_x, bins_y, big;
+    int cell_bin_stride, cell_chunk_stride;   // directory cell (bin, chunk) = cells[bin * cell_bin_stride + chunk * cell_chunk_stride]:
+                                              // bin-major for the start / count directory, CHUNK-major for the masked one (a set-up
+                                              // wave then stores its chunk's row contiguously; a tile reads one cell per thread either way)
 };
 
 // One entry of a bin's face list (also of the per-scene "big" list), 16 bytes.
@@ -34,18 +41,25 @@ struct GeomParams {
     int shared_faces;       // one topology for every scene of the batch (DIRT_FLAG_SHARED_FACES)
     FaceRec* recs;          // [B*F]
     FaceBox* boxes;         // [B*F]
-    BinCell* cells;         // [B][nchunk][MAX_BINS + 1] chunk x bin directory
+    BinCell* cells;         // [B][grid.big + 1][nchunk] bin x chunk directory
     BinEntry* entries;      // [B][nchunk][5 * chunk_faces] per-chunk entry segments, sorted by bin
+    TileRec* lrecs;  // [B*F] face-local coverage records (make_local_rec), setup_kernel_v2
+    float4* crecs;          // [B*F][3] the faces' vertex colours, padded to float4 (setup_kernel_v2, when vertex_colors and C in {1, 3, 4}), or nullptr
+    const float* vertex_colors;  // [B,V,C] or nullptr
+    int C;
     int B, V, F, H, W;
     int nchunk, chunk_faces;  // faces are processed in nchunk contiguous chunks per scene
     int masked;               // chunk_faces == 64: a directory cell is the 64-bit mask of the chunk's faces that touch the bin (filled by launch_geometry's callers: directory_is_masked)
+    int v2_only;              // the launch that follows is raster_kernel_v2: the {box, face} entries and the records' depth-plane tail are not written
     BinGrid grid;
 };
 
 struct RasterParams {
     const FaceRec* recs;         // [B*F] set-up records (workspace)
-    const BinCell* cells;        // [B][nchunk][MAX_BINS + 1] chunk x bin directory
+    const BinCell* cells;        // [B][grid.big + 1][nchunk] bin x chunk directory
     const BinEntry* entries;     // [B][nchunk][5 * chunk_faces] per-chunk entry segments, sorted by bin
+    const TileRec* lrecs; // [B*F] face-local coverage records (setup_kernel_v2)
+    const float4* crecs;         // [B*F][3] vertex colours per face (setup_kernel_v2), or nullptr
     int nchunk, chunk_faces;
     int masked;                  // the directory holds face masks, entries have fixed slots (chunks of 64 faces: setup_kernel_masked)
     const float* background;     // [B,H,W,C]
@@ -91,7 +105,7 @@ struct GradParams {
     float inv_w, inv_h;        // 1 / W, 1 / H (pixel -> NDC: ndc_of), filled by launch_grad
 };
 
-BinGrid make_bin_grid(int H, int W);
+BinGrid make_bin_grid(int H, int W, int nchunk, bool masked);
 void chunking(int F, int& nchunk, int& chunk_faces);
 #ifdef DIRT_NO_MASKED_DIR   // (A/B builds: rounds 1-4's start / count directory for every mesh)
 inline bool directory_is_masked(int) { return false; }
@@ -102,6 +116,9 @@ hipError_t launch_zero(void* b, size_t b_bytes, void* c, size_t c_bytes, hipStre
 hipError_t launch_unpack(const float* acc_gv, const float* acc_gvc, int acc_stride, float* gv, float* gvc, int C, size_t rows, hipStream_t stream);
 hipError_t launch_geometry(const GeomParams& g, hipStream_t stream);
 hipError_t launch_raster(const RasterParams& p, int B, bool visibility_only, hipStream_t stream);
+hipError_t launch_geometry_v2(const GeomParams& g, hipStream_t stream);   // dirt_forward.hip: masked directory, face-local records
+bool raster_v2_applies(const RasterParams& p, int B, bool visibility_only);   // ... the two-trip raster kernel (32 x 32 tiles, 1 / 3 / 4 channels or visibility)
+hipError_t launch_raster_v2(const RasterParams& p, int B, bool visibility_only, hipStream_t stream);
 hipError_t launch_grad(const GradParams& p, hipStream_t stream);
 hipError_t launch_grad_small(const GradParams& p, hipStream_t stream);  // dirt_grad_small.hip; p as filled by launch_grad
 hipError_t launch_grad_px2(const GradParams& p, hipStream_t stream);    // dirt_grad_px2.hip (two pixels per lane, 32 x 16 tiles); p as filled by launch_grad
