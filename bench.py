@@ -118,18 +118,40 @@ def main():
     distributed = world > 1
     ranks_seen = 1
     if distributed:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if share_gpu:
-            dist.init_process_group(backend='gloo')
-        else:
-            dist.init_process_group(backend='nccl', device_id=dev)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: what RCCL needs on this pool's host driver
+        # pre-flight: what this rank sees, before anything that can hang -- and one clear line if the node has fewer GPUs than ranks
+        n_dev = torch.cuda.device_count()
+        try:
+            rccl = '.'.join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            rccl = 'unavailable (%s)' % type(e).__name__
+        if rank == 0 or local_rank >= n_dev:
+            print('[bench pre-flight] rank %d/%d local_rank %d: torch.cuda.device_count() = %d, RCCL %s, HSA_ENABLE_IPC_MODE_LEGACY=%s, '
+                  'MASTER_ADDR=%s MASTER_PORT=%s, backend %s' % (rank, world, local_rank, n_dev, rccl, os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
+                                                                os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'),
+                                                                'gloo (DIRT_BENCH_SHARE_GPU)' if share_gpu else 'nccl'), file=sys.stderr, flush=True)
+        if not share_gpu and n_dev < int(os.environ.get('LOCAL_WORLD_SIZE', world)):
+            raise SystemExit('bench.py --gpus %d: this node exposes %d GPU(s) to rank %d (torch.cuda.device_count()); one rank per GPU is required '
+                             '(DIRT_BENCH_SHARE_GPU=1 exercises the control flow over gloo on one GPU)' % (world, n_dev, rank))
+        try:
+            if share_gpu:
+                dist.init_process_group(backend='gloo', timeout=datetime.timedelta(seconds=180))
+            else:
+                dist.init_process_group(backend='nccl', device_id=dev, timeout=datetime.timedelta(seconds=180))
+        except Exception as e:  # noqa: BLE001
+            raise SystemExit('bench.py: rank %d could not join the %s process group of %d ranks within 180 s (MASTER_ADDR=%s MASTER_PORT=%s): %s: %s'
+                             % (rank, 'gloo' if share_gpu else 'nccl (RCCL)', world, os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'),
+                                type(e).__name__, str(e)[:500]))
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)            # proof that RCCL sees every rank; outside the timed region
         ranks_seen = int(ones.item())
         assert ranks_seen == world, 'RCCL all-reduce saw %d of %d ranks' % (ranks_seen, world)
 
-    from dirt_amd import scenes, _lib, rasterise_ops as ops
+    from dirt_amd import _lib, rasterise_ops as ops
+    from tests import scenes
     _lib.load()
 
     F, H, W, C, seed0, r_lo, r_hi = scenes.CONFIGS[args.config]

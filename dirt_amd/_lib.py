@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DIRT_AMD_LIBRARY') or os.path.join(_HERE, 'libdirt_hip.so')  # override: instrumented builds (tools/)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 FLAG_Q1_INTENDED = 1
 FLAG_KEEP_STATE = 2
@@ -42,7 +42,7 @@ SYMBOLS = ('dirt_abi_version', 'dirt_last_error', 'dirt_workspace_bytes', 'dirt_
            'dirt_rasterise_backward', 'dirt_rasterise_visibility', 'dirt_state_grad_buffers', 'dirt_profile_count',
            'dirt_profile_name',
            'dirt_profile_read', 'dirt_profile_reset', 'dirt_texture_sample_forward', 'dirt_texture_sample_backward',
-           'dirt_texture_last_error')
+           'dirt_texture_sample_backward_image', 'dirt_texture_last_error')
 
 
 class DirtLibraryError(RuntimeError):
@@ -90,6 +90,8 @@ def load():
     lib.dirt_texture_sample_forward.restype = i
     lib.dirt_texture_sample_backward.argtypes = [fp, fp, fp, fp, fp, ll, i, i, i, i, i, u, vp]
     lib.dirt_texture_sample_backward.restype = i
+    lib.dirt_texture_sample_backward_image.argtypes = [fp, fp, fp, fp, fp, ll, ll, i, i, i, i, i, u, vp]
+    lib.dirt_texture_sample_backward_image.restype = i
     lib.dirt_texture_last_error.restype = ctypes.c_char_p
     if lib.dirt_abi_version() != ABI_VERSION:
         raise DirtLibraryError('libdirt_hip.so ABI %d != expected %d' % (lib.dirt_abi_version(), ABI_VERSION))

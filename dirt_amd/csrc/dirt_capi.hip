@@ -381,6 +381,7 @@ int dirt_rasterise_visibility(const float* vertices, const int32_t* faces, int32
     const Carved c = carved(workspace, w);
     const bool prof = (flags & DIRT_FLAG_PROFILE) != 0;
     dirt::GeomParams g = geom_params(c, vertices, faces, B, V, F, H, W, flags);
+    armed_set(workspace, nullptr, nullptr, false);   // the workspace is rebuilt: whatever a forward left cleared in it is forgotten
     dirt::RasterParams p = raster_params(c, g, 1, flags);
     p.vis = face_id;
     g.v2_only = dirt::raster_v2_applies(p, B, true) ? 1 : 0;

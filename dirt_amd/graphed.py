@@ -26,6 +26,14 @@ from . import rasterise_ops as ops
 __all__ = ['GraphedStep', 'backward']
 
 
+def _cell_has(cell):
+    try:
+        cell.cell_contents
+        return True
+    except ValueError:   # an empty cell
+        return False
+
+
 class GraphedStep:
     """rasterise_batch -> [loss_fn] -> gradients, captured as one HIP graph for the shapes of the given tensors.
 
@@ -44,15 +52,29 @@ class GraphedStep:
         for t in (background, vertices, vertex_colors):
             if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                 raise ValueError('GraphedStep binds float32, contiguous GPU tensors in place')
-        if not (faces.is_cuda and faces.dtype == torch.int32 and faces.is_contiguous()):
+        if not (isinstance(faces, torch.Tensor) and faces.is_cuda and faces.dtype == torch.int32 and faces.is_contiguous()):
             raise ValueError('GraphedStep: faces must be an int32, contiguous GPU tensor')
         if background.dim() != 4:
             raise ValueError('Rasterise expects background_tensor to be 4D, and bgcolor.shape == [None, height, width, channels]')
         if (loss_fn is None) == (grad_pixels is None):
             raise ValueError('GraphedStep needs exactly one of loss_fn and grad_pixels')
-        if grad_pixels is not None and not (grad_pixels.is_cuda and grad_pixels.dtype == torch.float32 and grad_pixels.is_contiguous()
-                                            and grad_pixels.shape == background.shape):
+        if grad_pixels is not None and not (isinstance(grad_pixels, torch.Tensor) and grad_pixels.is_cuda and grad_pixels.dtype == torch.float32
+                                            and grad_pixels.is_contiguous() and grad_pixels.shape == background.shape):
             raise ValueError('GraphedStep: grad_pixels must be a float32, contiguous GPU tensor of the image\'s shape')
+        bound = [t for t in (background, vertices, vertex_colors, faces, grad_pixels) if t is not None]
+        if any(t.device != background.device for t in bound):
+            raise ValueError('GraphedStep: all bound tensors must be on one device (%s)' % ', '.join(str(t.device) for t in bound))
+        # the graph reads and writes these very buffers: two of them sharing storage (grad_pixels aliasing the background, say)
+        # would make a replay read what the same replay overwrites
+        spans = [(t.untyped_storage().data_ptr() + t.storage_offset() * t.element_size(), t.numel() * t.element_size()) for t in bound]
+        for i in range(len(spans)):
+            for j in range(i + 1, len(spans)):
+                (a0, an), (b0, bn) = spans[i], spans[j]
+                if an and bn and a0 < b0 + bn and b0 < a0 + an:
+                    raise ValueError('GraphedStep: bound tensors must not share memory')
+        # tensors loss_fn closes over (a target image, say) are baked into the graph BY ADDRESS: they are kept alive here, and
+        # must be updated in place like the bound inputs
+        self._loss_closure = [c.cell_contents for c in (getattr(loss_fn, '__closure__', None) or ()) if _cell_has(c)]
         self.background, self.vertices, self.vertex_colors, self.faces = background, vertices, vertex_colors, faces
         self.grad_pixels, self.loss_fn = grad_pixels, loss_fn
         self._hwc = tuple(int(n) for n in background.shape[1:])

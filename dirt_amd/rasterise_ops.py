@@ -428,31 +428,56 @@ def _closure_identity(shader_fn):
     return (code if code is not None else id(shader_fn)), held
 
 
-def _ref(obj):
-    """A weak reference where the object allows one (tensors, modules, functions); else the object itself (ints, tuples:
-    small immutables whose identity cannot be recycled to mean something else while the entry compares them by value)."""
+class _Id:
+    """Identity of an object that cannot be weakly referenced (ints, strings, tuples, lists, dicts): its id and type -- never
+    the object itself (a closure over a list of tensors must not pin them) and never its value (`==` on user objects can
+    raise or synchronise the device: a list of tensors compares element-wise and then asks for a truth value)."""
+    __slots__ = ('ident', 'kind', 'parts')
+
+    def __init__(self, obj, depth):
+        self.ident, self.kind = id(obj), type(obj)
+        # one level into the common containers, so that a list rebuilt every step over the SAME tensors still matches
+        # and one over fresh tensors does not (an id alone can be recycled once the container is freed)
+        self.parts = None
+        if depth > 0 and isinstance(obj, (list, tuple)) and len(obj) <= 64:
+            self.parts = [_ref(o, depth - 1) for o in obj]
+        elif depth > 0 and isinstance(obj, dict) and len(obj) <= 64:
+            self.parts = [_ref(o, depth - 1) for o in obj.values()]
+
+
+def _ref(obj, depth=1):
+    """A weak reference where the object allows one (tensors, modules, functions); else an `_Id`."""
     import weakref
     try:
         return weakref.ref(obj)
     except TypeError:
-        return obj
+        return _Id(obj, depth)
+
+
+def _same_one(r, o, depth=1):
+    import weakref
+    if isinstance(r, weakref.ref):
+        return r() is not None and r() is o     # a dead referent never matches: ids of freed objects get reused, references do not
+    if r.kind is not type(o):
+        return False
+    if r.parts is not None:                     # a container: same length, same elements (by identity)
+        items = list(o.values()) if isinstance(o, dict) else (list(o) if isinstance(o, (list, tuple)) else None)
+        return items is not None and len(items) == len(r.parts) and all(_same_one(p, q, depth - 1) for p, q in zip(r.parts, items))
+    return r.ident == id(o)
 
 
 def _same(entry, held):
-    import weakref
-    if len(entry) != len(held):
-        return False
-    for r, o in zip(entry, held):
-        if isinstance(r, weakref.ref):
-            if r() is None or r() is not o:     # a dead referent never matches: ids of freed objects get reused, references do not
-                return False
-        elif r is not o and r != o:
-            return False
-    return True
+    """Strictly by identity: no `==` on anything a shader closes over."""
+    return len(entry) == len(held) and all(_same_one(r, o) for r, o in zip(entry, held))
+
+
+_walk_limit_warned = set()   # code objects whose graph walk has been switched off (warned once each)
 
 
 def _shader_needs_walk(shader_fn):
-    """True the first time this (code, closure) is seen -- and only for the first _WALKS_PER_CODE closures of a code object."""
+    """True the first time this (code, closure) is seen -- and only for the first _WALKS_PER_CODE closures of a code object:
+    beyond that (a lambda re-created every step over fresh tensors) the check is switched off for that code object, with
+    one warning saying so."""
     code, held = _closure_identity(shader_fn)
     entries = _checked_shaders.get(code)
     if entries is None:
@@ -463,6 +488,13 @@ def _shader_needs_walk(shader_fn):
     if any(_same(e, held) for e in entries):
         return False
     if len(entries) >= _WALKS_PER_CODE:
+        if code not in _walk_limit_warned:
+            if len(_walk_limit_warned) < _CHECKED_SHADERS_MAX:
+                _walk_limit_warned.add(code)
+            import warnings
+            warnings.warn('rasterise_deferred: %d different closures of one shader function have been checked for tensors that '
+                          'require grad but are not listed in shader_additional_inputs / shader_parameters; further closures of '
+                          'it are not checked (the check walks the autograd graph on the host).' % _WALKS_PER_CODE, stacklevel=4)
         return False
     entries.append([_ref(o) for o in held])
     return True

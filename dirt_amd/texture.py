@@ -96,10 +96,14 @@ class _SampleTextureUV(torch.autograd.Function):
         grad_out = grad_out.contiguous().to(torch.float32)
         grad_texture = torch.empty_like(texture)
         grad_uvs = torch.empty(uv_shape, dtype=torch.float32, device=texture.device) if ctx.needs_input_grad[1] else None
+        # the look-ups as an image: the last pixel axis is a row, everything before it stacks rows ([H, W, 2]; [B, H, W, 2]);
+        # a flat [n, 2] list is one row
+        cols = int(uv_shape[-2]) if len(uv_shape) >= 3 else n
+        rows = n // cols if cols else 0
         with _ops._on_device(texture.device):
-            rc = lib.dirt_texture_sample_backward(texture.data_ptr(), src.data_ptr(), grad_out.data_ptr(), grad_texture.data_ptr(),
-                                                  grad_uvs.data_ptr() if grad_uvs is not None else None, n, ht, wt, ct, stride, 2, flags,
-                                                  _ops._stream_handle(texture.device))
+            rc = lib.dirt_texture_sample_backward_image(texture.data_ptr(), src.data_ptr(), grad_out.data_ptr(), grad_texture.data_ptr(),
+                                                        grad_uvs.data_ptr() if grad_uvs is not None else None, rows, cols, ht, wt, ct, stride, 2,
+                                                        flags, _ops._stream_handle(texture.device))
         if rc:
             raise ValueError(lib.dirt_texture_last_error().decode())
         return grad_texture, grad_uvs, None

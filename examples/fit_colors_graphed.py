@@ -17,7 +17,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import dirt_amd  # noqa: E402
-from dirt_amd import scenes  # noqa: E402
+from tests import scenes  # noqa: E402
 
 
 def fit(device, height=256, width=256, faces=400, steps=60, lr_color=200.0, lr_shift=2.0e-3, verbose=True):

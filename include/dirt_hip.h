@@ -13,7 +13,19 @@
  *   - background / pixels / grad_* images are [B,H,W,C], top row first (README.md:183);
  *     vertices [B,V,4] are OpenGL clip-space (x,y,z,w); vertex_colors [B,V,C]; faces [B,F,3];
  *   - `workspace` is caller-owned device scratch of at least dirt_workspace_bytes(...) bytes,
- *     16-byte aligned; the library keeps no device state between calls (re-entrant);
+ *     16-byte aligned; the library keeps no DEVICE state between calls.  Calls on different workspaces are independent
+ *     (any threads, any streams).  ONE workspace is a single-stream object: the calls that share it -- a forward with
+ *     DIRT_FLAG_KEEP_STATE and the backward calls with DIRT_FLAG_REUSE_STATE that consume it -- must be enqueued on one
+ *     stream (or be ordered by the caller's own events): nothing in the library serialises two streams on one workspace;
+ *   - the one piece of HOST state: per workspace address, which gradient buffers the last forward left cleared (see
+ *     DIRT_FLAG_OUTPUTS_CLEARED / DIRT_FLAG_DENSE_FROM_STATE).  It is consulted at ENQUEUE time and knows pointers, not
+ *     contents -- so the "skip the clearing launch" paths additionally require that (i) forward and backward are captured
+ *     TOGETHER when a HIP graph is recorded (a backward captured alone replays without its forward's clear and would
+ *     accumulate), (ii) the cleared tensors stay allocated between the two calls (a caching allocator handing the same
+ *     addresses to other tensors in between is indistinguishable), and (iii) nothing writes to them in between.  The
+ *     Python wrapper keeps the tensors on the state object, which guarantees (ii) and (iii); a caller that cannot, omits
+ *     the flags and pays one clearing launch.  Any call that rebuilds a workspace (a forward, a stateless backward,
+ *     dirt_rasterise_visibility) forgets what was cleared in it;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); work is enqueued
  *     asynchronously on it and the call returns without synchronising;
  *   - the current HIP device must be the one that owns the pointers;
@@ -30,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DIRT_ABI_VERSION 3
+#define DIRT_ABI_VERSION 4
 
 /* error codes */
 #define DIRT_OK 0
@@ -212,6 +224,14 @@ int dirt_texture_sample_forward(const float *texture, const float *uvs, float *o
 int dirt_texture_sample_backward(const float *texture, const float *uvs, const float *grad_out, float *grad_texture,
                                  float *grad_uvs, long long n, int Ht, int Wt, int Ct, int uv_stride, int grad_uv_stride,
                                  unsigned flags, void *stream);
+/* The same gradient for look-ups that form an IMAGE -- rows x cols pixels, row-major, n = rows * cols pairs (a G-buffer slice
+ * [H, W, 2]; batches stack their rows): the kernel then works on 16 x 16-pixel tiles, sums a tile's contributions in an LDS copy
+ * of the texture patch they fall into and sends every texel of the patch to memory once -- instead of 4 Ct float atomics
+ * per pixel (what `gather_nd`'s gradient in the reference and dirt_texture_sample_backward's flat runs of 256 amount to where
+ * neighbouring pixels share texels).  Same results to summation order. */
+int dirt_texture_sample_backward_image(const float *texture, const float *uvs, const float *grad_out, float *grad_texture,
+                                       float *grad_uvs, long long rows, long long cols, int Ht, int Wt, int Ct, int uv_stride,
+                                       int grad_uv_stride, unsigned flags, void *stream);
 const char *dirt_texture_last_error(void);
 
 /*

@@ -12,7 +12,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import oracle  # noqa: E402
-from dirt_amd import scenes, rasterise_ops as ops  # noqa: E402
+from dirt_amd import rasterise_ops as ops
+from tests import scenes  # noqa: E402
 from tests import parity  # noqa: E402
 
 

@@ -20,7 +20,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-from dirt_amd import scenes  # noqa: E402
+from tests import scenes  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

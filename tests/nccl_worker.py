@@ -11,7 +11,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from dirt_amd import scenes, sharding  # noqa: E402
+from dirt_amd import sharding
+from tests import scenes  # noqa: E402
 from dirt_amd import rasterise_ops as ops  # noqa: E402
 
 
@@ -19,7 +20,8 @@ def main():
     rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    dist.init_process_group('nccl', device_id=dev)
+    import datetime
+    dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=180))
     n_scenes, H, W, C = 5, 96, 128, 3
     base = scenes.rand_scene(300, H, W, C, 31, 0.03, 0.25, True)
     rng = np.random.default_rng(7)   # the same on every rank: a replicated batch, of which each rank takes its share
@@ -41,6 +43,18 @@ def main():
         print('nccl_worker ok: %d ranks, %d scenes' % (world, n_scenes))
     else:
         assert full is None
+    # the collectives themselves on device tensors, whatever the world size (a world of ONE still initialises RCCL, its IPC
+    # path and the device-side kernels for real: what the one-GPU boxes can exercise)
+    ones = torch.ones(4, device=dev)
+    dist.all_reduce(ones)
+    assert torch.equal(ones.cpu(), torch.full((4,), float(world)))
+    dist.broadcast(ones, src=0)
+    piece = torch.full((3,), float(rank), device=dev)
+    bufs = [torch.empty_like(piece) for _ in range(world)] if rank == 0 else None
+    dist.gather(piece, bufs, dst=0)
+    if rank == 0:
+        assert all(torch.equal(b.cpu(), torch.full((3,), float(r))) for r, b in enumerate(bufs))
+        print('nccl_worker collectives ok: RCCL %s' % '.'.join(str(x) for x in torch.cuda.nccl.version()))
     dist.barrier()
     dist.destroy_process_group()
 

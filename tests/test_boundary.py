@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(syms) == set(_lib.SYMBOLS), (syms, _lib.SYMBOLS)
     for s in syms:
         assert hasattr(lib, s), 'libdirt_hip.so does not export %s' % s
-    assert lib.dirt_abi_version() == 3
+    assert lib.dirt_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_python_flag_constants_match_the_header():
@@ -174,7 +174,7 @@ def test_channel_groups_follow_the_reference():
 
 
 def test_scene_generators_are_deterministic():
-    from dirt_amd import scenes
+    from tests import scenes
     a, b = scenes.config_scene('K3'), scenes.config_scene('K3')
     assert all(np.array_equal(a[k], b[k]) for k in ('vertices', 'faces', 'vertex_colors', 'background', 'grad_pixels'))
     assert a['vertices'].shape == (30000, 4) and a['faces'].shape == (10000, 3) and a['background'].shape == (1024, 1024, 4)

@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from dirt_amd import scenes, sharding
+from dirt_amd import sharding
+from tests import scenes
 from dirt_amd import rasterise_ops as ops
 from tests import parity
 
@@ -153,6 +154,23 @@ def test_two_gpus_over_rccl(gpu):
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
                           '--master-port', str(port), worker], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'nccl_worker ok' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_one_rank_nccl_group_on_one_gpu(gpu):
+    """A process group of ONE rank over RCCL on the one GPU every box has: `init_process_group('nccl', device_id=...)`, the
+    dmabuf IPC setting, an all-reduce, a broadcast and a gather on device tensors, the sharded render + gather of
+    tests/nccl_worker.py -- everything `bench.py --gpus N` does first, run for real (the two-GPU test above is skipped on
+    one-GPU boxes; the host logic at world sizes 2 and 4 is tests/test_distributed.py over gloo)."""
+    import subprocess
+    import sys
+    import socket
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'nccl_worker.py')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), worker], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'nccl_worker ok' in out.stdout and 'nccl_worker collectives ok' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 # ---- the reference's own test scenes ----------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from dirt_amd import scenes
+from tests import scenes
 from dirt_amd import rasterise_ops as ops
 from tests import parity
 
@@ -439,3 +439,60 @@ def test_graphed_optimisation_example_reduces_the_loss(gpu):
     history = ex.fit(gpu, steps=40, verbose=False)
     assert np.isfinite(history).all()
     assert history[-1] < 0.5 * history[0], (history[0], history[-1])
+
+
+# ---- the kernel-selection table: the library's own choice must be (close to) the fastest eligible shape ---------------
+
+def _time_shapes(config, gpu, flag_sets, steps=60, reps=3):
+    """{name: (raster us, gradient us)}: the library's per-kernel HIP-event averages of forward + backward steps of `config`
+    under each flag set (min over `reps` repetitions of `steps` steps)."""
+    from dirt_amd import _lib
+    s = scenes.config_scene(config)
+    H, W, C = s['background'].shape
+    t = {k: torch.from_numpy(np.ascontiguousarray(s[k]))[None].to(gpu) for k in ('background', 'vertices', 'vertex_colors', 'faces', 'grad_pixels')}
+    out = {}
+    for name, flags in flag_sets:
+        def step(fl):
+            px, st = ops._op_rasterise(t['background'], t['vertices'], t['vertex_colors'], t['faces'], H, W, C, flags=fl, keep_state=True, dense_grads=True)
+            ops._op_rasterise_grad(t['vertices'], t['faces'], px, t['grad_pixels'], H, W, C, flags=fl, state=st, state_outputs='dense')
+        for _ in range(10):
+            step(flags)
+        best = None
+        for _ in range(reps):
+            _lib.profile_reset()
+            torch.cuda.synchronize()
+            for _ in range(steps):
+                step(flags | _lib.FLAG_PROFILE)
+            torch.cuda.synchronize()
+            prof = {k: ms / n * 1e3 for k, (ms, n) in _lib.profile_read().items() if n}
+            cur = (prof.get('raster_kernel<shade>', 0.0), prof.get('grad_kernel', 0.0))
+            best = cur if best is None else (min(best[0], cur[0]), min(best[1], cur[1]))
+        out[name] = best
+    return out
+
+
+@pytest.mark.parametrize('config', ['K3', 'K3-768', 'K3-3ch', 'K3-256', 'K3-2048'])
+def test_library_picks_the_fastest_kernel_shape(gpu, config):
+    """launch_grad / launch_raster choose among kernel shapes by thresholds that were measured once (dirt_grad.hip, dirt_raster.hip,
+    dirt_forward.hip).  Here every eligible shape is timed on the BASELINE configurations and the library's own choice
+    (flags = 0) must be within 5 % of the fastest (+ 0.7 us: the event pairs' own jitter) -- so a kernel change that moves a
+    crossover fails a test instead of leaving a stale table behind."""
+    from dirt_amd import _lib
+    C = scenes.CONFIGS[config][3]
+    grad_sets = [('auto', 0), ('pairs', _lib.FLAG_GRAD_PAIRS), ('rows', _lib.FLAG_GRAD_ROWS)]
+    if C in (1, 3, 4):
+        grad_sets += [('px2', _lib.FLAG_GRAD_PX2), ('small', _lib.FLAG_GRAD_SMALL)]
+    if C == 4:
+        grad_sets += [('stream', _lib.FLAG_GRAD_STREAM)]
+    tile_sets = [('auto', 0), ('large', _lib.FLAG_TILES_LARGE), ('small', _lib.FLAG_TILES_SMALL)]
+    for attempt in range(2):
+        g = _time_shapes(config, gpu, grad_sets)
+        r = _time_shapes(config, gpu, tile_sets)
+        best_g = min(v[1] for v in g.values())
+        best_r = min(v[0] for v in r.values())
+        ok = g['auto'][1] <= 1.05 * best_g + 0.7 and r['auto'][0] <= 1.05 * best_r + 0.7
+        if ok:
+            break
+    report = '%s: gradient %s | raster %s' % (config, {k: round(v[1], 1) for k, v in g.items()}, {k: round(v[0], 1) for k, v in r.items()})
+    print(report)
+    assert ok, 'the library\'s choice is more than 5 %% slower than another eligible shape -- ' + report

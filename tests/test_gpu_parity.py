@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from dirt_amd import scenes
+from tests import scenes
 from dirt_amd import rasterise_ops as ops
 from tests import parity
 

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from dirt_amd import lighting, matrices, projection, scenes
+from dirt_amd import lighting, matrices, projection
+from tests import scenes
 
 
 def _np_rodrigues(v):
@@ -281,5 +282,39 @@ def test_shader_walk_tells_closures_of_one_factory_apart():
     # the training-loop pattern: a fresh lambda over fresh tensors every step is walked at most _WALKS_PER_CODE times
     ops._checked_shaders.clear()
     keep = [torch.ones(2, requires_grad=True) for _ in range(10)]
-    assert sum(ops._shader_needs_walk(factory(t)) for t in keep) == ops._WALKS_PER_CODE
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        ops._walk_limit_warned.clear()
+        assert sum(ops._shader_needs_walk(factory(t)) for t in keep) == ops._WALKS_PER_CODE
+    assert sum('further closures' in str(w.message) for w in caught) == 1   # said once that the check is off for this code object
+    ops._checked_shaders.clear()
+
+
+def test_shader_walk_compares_closures_by_identity_only():
+    """A shader that closes over a LIST (tuple, dict) of tensors rebuilt every step: the cache must tell the closures apart
+    by the identity of what they hold -- never by `==`, which on lists of multi-element tensors raises 'Boolean value of
+    Tensor with more than one value is ambiguous' and on one-element tensors synchronises the device -- and must not keep the
+    containers (hence the tensors) alive."""
+    import gc
+    import weakref
+    from dirt_amd import rasterise_ops as ops
+    ops._checked_shaders.clear()
+
+    def factory(ws):
+        return lambda g: g * ws[0]
+
+    a, b = torch.ones(5, requires_grad=True), torch.ones(5, requires_grad=True)
+    assert ops._shader_needs_walk(factory([a, b]))
+    assert not ops._shader_needs_walk(factory([a, b]))          # another list object over the same tensors: the same closure
+    assert ops._shader_needs_walk(factory([a, torch.ones(5)]))   # ... over another tensor: a new one (and no exception)
+    assert ops._shader_needs_walk(factory((a, b)))               # a tuple is not a list
+    # nothing a shader closes over is kept alive by the cache
+    t = torch.ones(7, requires_grad=True)
+    r = weakref.ref(t)
+    ops._checked_shaders.clear()
+    assert ops._shader_needs_walk(factory([t]))
+    del t
+    gc.collect()
+    assert r() is None
     ops._checked_shaders.clear()

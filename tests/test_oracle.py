@@ -15,7 +15,7 @@ import os
 import numpy as np
 import pytest
 
-from dirt_amd import scenes
+from tests import scenes
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 

@@ -16,7 +16,7 @@ import os
 import numpy as np
 import pytest
 
-from dirt_amd import scenes
+from tests import scenes
 from tests.golden import make_golden
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')

@@ -21,7 +21,7 @@ import dirt
 import dirt.lighting
 import dirt.matrices
 import dirt.rasterise_ops
-from dirt_amd import scenes
+from tests import scenes
 from tests import parity
 
 pytestmark = pytest.mark.gpu

@@ -98,3 +98,41 @@ def test_argument_shapes_are_checked():
         tex.sample_texture_uv(torch.zeros(4, 4, 3), torch.zeros(5, 3))
     with pytest.raises(ValueError):
         tex.sample_texture_uv(torch.zeros(4, 4), torch.zeros(5, 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ct', [1, 3, 4, 5])
+@pytest.mark.parametrize('mode', ['repeat', 'clamp'])
+def test_gradient_of_a_smooth_uv_image_takes_the_patch_path(gpu, ct, mode):
+    """The backward kernel works on 16 x 16-pixel tiles of the look-up image and sums each tile's contributions in an LDS copy of
+    the texture patch they fall into (dirt_texture.hip, round 6); tiles whose patch is too large -- the `repeat` seam of this
+    field, random coordinates -- scatter float atomics as before.  A smooth, rotated (u, v) field with a seam across the
+    frame exercises both, for every channel-count specialisation (1, 3, 4; 5 = the generic passes), an odd image size and a
+    batch of two images; values against the oracle's float64 gradient."""
+    from dirt_amd import texture
+    rng = np.random.default_rng(11 + ct)
+    H, W, Ht, Wt = 75, 93, 64, 48
+    tex = rng.uniform(0, 1, (Ht, Wt, ct)).astype(np.float32)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
+    uvs = []
+    for b, (ang, scale) in enumerate(((0.3, 1.7), (-0.2, 0.6))):
+        c, s = np.cos(ang), np.sin(ang)
+        u = (c * xs / W + s * ys / H) * scale - 0.2
+        v = (-s * xs / W + c * ys / H) * scale + 0.1
+        uvs.append(np.stack([u, v], -1))
+    uv = np.stack(uvs).astype(np.float32)                     # [2, H, W, 2]
+    g = rng.standard_normal((2, H, W, ct)).astype(np.float32)
+    t = torch.from_numpy(tex).to(gpu).requires_grad_(True)
+    u_t = torch.from_numpy(uv).to(gpu).requires_grad_(True)
+    out = texture.sample_texture_uv(t, u_t, mode)
+    assert np.array_equal(out.detach().cpu().numpy().view(np.uint32), tex_oracle.sample_texture_uv(tex, uv, mode).view(np.uint32))
+    out.backward(torch.from_numpy(g).to(gpu))
+    want_t, want_uv = tex_oracle.sample_texture_uv_grad(tex, uv, g, mode)
+    assert float(np.abs(t.grad.cpu().numpy() - want_t).max()) <= 2e-5 * max(1.0, float(np.abs(want_t).max()))
+    assert float(np.abs(u_t.grad.cpu().numpy() - want_uv).max()) <= 1e-4 * max(1.0, float(np.abs(want_uv).max()))
+    # nearest: the gradient of a gather
+    t2 = torch.from_numpy(tex).to(gpu).requires_grad_(True)
+    texture.sample_texture_uv(t2, torch.from_numpy(uv).to(gpu), mode, 'nearest').backward(torch.from_numpy(g).to(gpu))
+    t3 = torch.from_numpy(tex).to(gpu).requires_grad_(True)
+    texture.sample_texture(t3, texture.uvs_to_pixel_indices(torch.from_numpy(uv).to(gpu), t3.shape[:2], mode), 'nearest').backward(torch.from_numpy(g).to(gpu))
+    assert torch.allclose(t2.grad, t3.grad, atol=2e-5 * max(1.0, float(t3.grad.abs().max())), rtol=1e-5)

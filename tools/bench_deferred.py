@@ -10,7 +10,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-from dirt_amd import scenes, rasterise_ops as ops  # noqa: E402
+from dirt_amd import rasterise_ops as ops
+from tests import scenes  # noqa: E402
 
 
 def main():

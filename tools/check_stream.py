@@ -11,7 +11,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import oracle  # noqa: E402
-from dirt_amd import _lib, scenes, rasterise_ops as ops  # noqa: E402
+from dirt_amd import _lib, rasterise_ops as ops
+from tests import scenes  # noqa: E402
 from tests import parity  # noqa: E402
 
 STREAM = _lib.FLAG_GRAD_STREAM

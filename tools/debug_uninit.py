@@ -2,7 +2,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from dirt_amd import scenes, _lib
+from dirt_amd import _lib
+from tests import scenes
 dev = torch.device('cuda:0')
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 lib = _lib.load()

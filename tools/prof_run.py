@@ -1,6 +1,7 @@
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from dirt_amd import scenes, rasterise_ops as ops
+from dirt_amd import rasterise_ops as ops
+from tests import scenes
 dev = torch.device('cuda:0')
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'K3'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10

@@ -3,7 +3,8 @@ usage (GPU box): python tools/profile_autograd.py [steps]"""
 import cProfile, io, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from dirt_amd import scenes, rasterise_ops as ops
+from dirt_amd import rasterise_ops as ops
+from tests import scenes
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 F, H, W, C, seed, lo, hi = scenes.CONFIGS['K3']

@@ -3,7 +3,8 @@ usage (GPU box): python tools/profile_host.py [steps]"""
 import cProfile, pstats, sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
-from dirt_amd import scenes, _lib, rasterise_ops as ops
+from dirt_amd import _lib, rasterise_ops as ops
+from tests import scenes
 _lib.load()
 F, H, W, C, seed0, r_lo, r_hi = scenes.CONFIGS['K3']
 b = scenes.batch_scene(F, H, W, C, [seed0], r_lo=r_lo, r_hi=r_hi)

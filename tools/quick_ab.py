@@ -9,7 +9,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-from dirt_amd import _lib, scenes, rasterise_ops as ops  # noqa: E402
+from dirt_amd import _lib, rasterise_ops as ops
+from tests import scenes  # noqa: E402
 
 configs = (sys.argv[1] if len(sys.argv) > 1 else 'K3').split()
 flagsets = [int(x, 0) for x in (sys.argv[2] if len(sys.argv) > 2 else '0').split()]

@@ -3,7 +3,8 @@ usage: python tools/step_ramp.py [K]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from dirt_amd import scenes, _lib, rasterise_ops as ops
+from dirt_amd import _lib, rasterise_ops as ops
+from tests import scenes
 _lib.load()
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 F, H, W, C, seed0, r_lo, r_hi = scenes.CONFIGS['K3']

@@ -3,7 +3,8 @@ of the library's own per-kernel profile).  usage: python tools/time_variants.py 
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from dirt_amd import _lib, scenes, rasterise_ops as ops
+from dirt_amd import _lib, rasterise_ops as ops
+from tests import scenes
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'K3'
 F, H, W, C, seed, rlo, rhi = scenes.CONFIGS[cfg]

@@ -3,7 +3,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import oracle
-from dirt_amd import scenes, rasterise_ops as ops
+from dirt_amd import rasterise_ops as ops
+from tests import scenes
 dev = torch.device('cuda:0')
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 

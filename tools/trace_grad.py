@@ -3,7 +3,8 @@ usage: python tools/trace_grad.py [config]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from dirt_amd import _lib, scenes, rasterise_ops as ops
+from dirt_amd import _lib, rasterise_ops as ops
+from tests import scenes
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'K3'
 lib = _lib.load()

@@ -3,7 +3,8 @@ usage: python tools/trace_stream.py [config] [scenes]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from dirt_amd import _lib, scenes, rasterise_ops as ops
+from dirt_amd import _lib, rasterise_ops as ops
+from tests import scenes
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'K3'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
