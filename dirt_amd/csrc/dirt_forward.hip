@@ -219,8 +219,11 @@ static_assert(sizeof(ShadeSlot<true>) == 144 && sizeof(ShadeSlot<false>) == 96, 
 // p.state_a); MODE 1 is the visibility pass (p.vis and / or the state; no colours).  32 x 32-pixel tiles, four waves, each
 // owning a 16 x 16 region = 2 x 2 blocks of 8 x 8 pixels (one pixel of every block per lane), from the coverage loop to the
 // stores: dirt_raster.hip's decomposition.
+#ifndef DIRT_V2_WAVES
+#define DIRT_V2_WAVES 4
+#endif
 template <int MODE, int CSPEC>
-__global__ __launch_bounds__(RTHREADS, 4) void raster_kernel_v2(RasterParams p)
+__global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(RasterParams p)
 {
     constexpr int NB = 2, TILE = 32, PPL = 4;
     constexpr bool COLOURS = MODE == 0;
@@ -367,13 +370,34 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel_v2(RasterParams p)
                 if (box.i_max >= rx0 && box.i_min <= rx0 + 15 && box.r_max >= ry0 && box.r_min <= ry0 + 15) {
                     const uint32_t rowbits = (bx0 == 0 ? 1u : 0u) | (bx1 == 1 ? 2u : 0u);
                     mym4 = (by0 == 0 ? rowbits : 0u) | (by1 == 1 ? rowbits << 2 : 0u);
+#ifndef DIRT_NO_BLOCK_CULL
+                    // ... minus the blocks the TRIANGLE misses although its box touches them (about every third): an edge function is
+                    // linear, so its largest value over a block's 8 x 8 samples is at a corner sample; if that is below -bound -- the
+                    // float32 form's certified error, so the exact value is negative too -- no sample of the block is inside that
+                    // edge.  One lane per candidate, 64 candidates at once: ~60 instructions that save whole passes of the serial loop
+                    // below.  (NaN coefficients or bound: no comparison holds, nothing is culled.)
+                    const TileRec& t = s_rec[idx];
+                    const float nb = -t.bound;
+#pragma unroll
+                    for (int by = 0; by < 2; ++by) {
+                        const float dy_hi = (float)((int)box.r_min - (ry0 + 8 * by)), dy_lo = dy_hi - 7.f;     // dy = r_min - r over the block's rows
+#pragma unroll
+                        for (int bx = 0; bx < 2; ++bx) {
+                            const float dx_lo = (float)(rx0 + 8 * bx - (int)box.i_min), dx_hi = dx_lo + 7.f;   // dx = x - i_min over the block's columns
+                            bool out = false;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const float e = fmaf(t.a[k], t.a[k] > 0.f ? dx_hi : dx_lo, fmaf(t.b[k], t.b[k] > 0.f ? dy_hi : dy_lo, t.c[k]));
+                                out |= e < nb;
+                            }
+                            if (out) mym4 &= ~(1u << (2 * by + bx));
+                        }
+                    }
+#endif
                 }
             }
             unsigned long long m = __builtin_amdgcn_ballot_w64(mym4 != 0);
-            while (m) {
-                const int k = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const TileRec t = s_rec[cb + k];
+            auto visit = [&](const TileRec& t, int k) {
                 const uint32_t m4 = (uint32_t)__builtin_amdgcn_readlane((int)mym4, k);
                 // sample offsets from the face's origin (the top-left pixel of its box): exact small integers
                 float dxl[NB], dyl[NB];
@@ -386,6 +410,15 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel_v2(RasterParams p)
 #ifdef DIRT_TRACE
                 ++tr_cand;
 #endif
+            };
+            // (no software prefetch of the next candidate's record -- two candidates per trip, the second record requested before
+            // the first is worked on, measured the same within noise at K3, K3-2048 and eight scenes per launch for 19 more
+            // registers: profiles/EXPERIMENTS.md round 6)
+            while (m) {
+                const int k = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const TileRec t = s_rec[cb + k];
+                visit(t, k);
             }
         }
         FMARK();  // 7 coverage loop done

@@ -762,7 +762,12 @@ __global__ __launch_bounds__(GTHREADS, CSPEC == 6 ? DIRT_TWO3_WAVES : (AI ? 5 : 
                         }
                     }
                 }
+#ifdef DIRT_SCHARR_PAIRS   // (A/B build: two channels' taps in flight)
+                if ((ch & 1) || ch == NCH - 1) __builtin_amdgcn_sched_barrier(0);
+#elif defined(DIRT_SCHARR_FREE)
+#else
                 __builtin_amdgcn_sched_barrier(0);  // one channel's taps at a time
+#endif
             }
         }
         GMARK();  // 4 Scharr done
