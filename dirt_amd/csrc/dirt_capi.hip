@@ -156,7 +156,7 @@ Workspace carve(int B, int V, int F, int H, int W, int C)
     int nchunk, chunk_faces;
     dirt::chunking(F, nchunk, chunk_faces);
     const bool masked = dirt::directory_is_masked(chunk_faces);
-    w.cells_off = off;   off = align_up(off + (size_t)B * nchunk * ((masked ? dirt::MAX_BINS_MASKED : dirt::MAX_BINS) + 1) * sizeof(dirt::BinCell), 256);
+    w.cells_off = off;   off = align_up(off + (size_t)B * nchunk * ((masked ? dirt::MAX_BINS_MASKED + 1 : dirt::MAX_BINS) + 1) * sizeof(dirt::BinCell), 256);
     w.entries_off = off; off = align_up(off + (size_t)B * nchunk * 5 * (size_t)chunk_faces * sizeof(dirt::BinEntry), 256);
     // (masked directory, setup_kernel_v2: per face its face-local coverage record and its three vertex colours as float4s)
     w.lrecs_off = off;   off = align_up(off + (masked ? (size_t)B * F * sizeof(dirt::TileRec) : 0), 256);

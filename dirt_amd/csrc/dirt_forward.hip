@@ -74,12 +74,12 @@ __device__ __forceinline__ uint32_t lds_address(T* p)
 template <int CK>
 __global__ __launch_bounds__(64) void setup_kernel_v2(GeomParams g)
 {
-    __shared__ unsigned long long s_mask[MAX_BINS_MASKED + 1];    // [grid.big] = big faces
+    __shared__ __align__(16) unsigned long long s_mask[MAX_BINS_MASKED + 2];    // [grid.big] = big faces
     const int ib = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
     FTRACE_DECL();
     FMARK();  // 0 start
     const int nbins = g.grid.bins_x * g.grid.bins_y, big = g.grid.big;
-    BinCell* __restrict__ row = g.cells + ((size_t)ib * g.nchunk + chunk) * (size_t)(big + 1);   // chunk-major: this chunk's cells are contiguous
+    BinCell* __restrict__ row = g.cells + ((size_t)ib * g.nchunk + chunk) * (size_t)g.grid.cell_chunk_stride;   // chunk-major: this chunk's cells are contiguous
     const int f = chunk * 64 + lane;
     const bool have = f < g.F && g.V > 0;
     if (g.F == 0 || g.V <= 0) {   // (uniform) nothing to set up: an all-zero row is what the raster kernel reads
@@ -168,9 +168,15 @@ __global__ __launch_bounds__(64) void setup_kernel_v2(GeomParams g)
     FMARK();  // 3 set-up, record stores, masks
     __syncthreads();
     FMARK();  // 4
-    for (int i = lane; i < nbins; i += 64) {
-        const unsigned long long m = s_mask[i];
-        row[i] = BinCell{(uint32_t)m, (uint32_t)(m >> 32)};
+    // (two cells per lane and store: 16-byte accesses on both sides; the row starts at a 16-byte boundary)
+    for (int i = 2 * lane; i < nbins; i += 128) {
+        if (i + 1 < nbins) {
+            const ulonglong2 m = *reinterpret_cast<const ulonglong2*>(&s_mask[i]);
+            *reinterpret_cast<ulonglong2*>(&row[i]) = m;
+        } else {
+            const unsigned long long m = s_mask[i];
+            row[i] = BinCell{(uint32_t)m, (uint32_t)(m >> 32)};
+        }
     }
     if (lane == 63) {
         const unsigned long long m = s_mask[big];
@@ -200,7 +206,10 @@ hipError_t launch_geometry_v2(const GeomParams& g, hipStream_t stream)
 // ---- raster ----------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int V2_CAP = 96;       // candidates per round whose records live in LDS
+#ifndef DIRT_V2_CAP
+#define DIRT_V2_CAP 96
+#endif
+constexpr int V2_CAP = DIRT_V2_CAP;       // candidates per round whose records live in LDS
 
 // What the shading pass reads of a candidate, as LDS-DMA leaves it: the head of its FaceRec, then (MODE 0) its colours.
 template <bool COLOURS>
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
     // ---- trip 1: this tile's cell of every chunk -- the mask of the chunk's faces that touch the tile's bin -- and the
     //      chunk's mask of "big" faces.  One chunk per thread (<= 256 chunks of 64 faces). ----
     const int bin = (tr0 >> p.grid.shift) * p.grid.bins_x + (tx0 >> p.grid.shift);
-    const BinCell* __restrict__ cells = p.cells + (size_t)ib * p.nchunk * (size_t)(p.grid.big + 1);
+    const BinCell* __restrict__ cells = p.cells + (size_t)ib * p.nchunk * (size_t)p.grid.cell_chunk_stride;
     unsigned long long m_bin = 0ull, m_big = 0ull;
     if (tid < p.nchunk) {
         const BinCell* __restrict__ rowc = cells + (size_t)tid * p.grid.cell_chunk_stride;   // (chunk-major: cell_bin_stride is 1)
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
 
         // ---- trip 2: the candidates' coverage records, 16-byte piece idx = 5 slot + part, lane-linear into s_rec ----
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < (5 * V2_CAP + RTHREADS - 1) / RTHREADS; ++k) {
             const int idx = tid + RTHREADS * k;
             if (idx < 5 * n) {
                 const int slot = idx / 5, part = idx - 5 * slot;
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
         //      part: the six pieces of the set-up record's head, then the three colours ----
         if (round == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < (SPARTS * V2_CAP + RTHREADS - 1) / RTHREADS; ++k) {
                 const int idx = tid + RTHREADS * k;
                 if (idx < SPARTS * n) {
                     const int slot = idx / SPARTS, part = idx - SPARTS * slot;

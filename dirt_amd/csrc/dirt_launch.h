@@ -9,7 +9,10 @@ namespace dirt {
 struct TileRec;   // dirt_raster_common.h
 
 constexpr int MAX_BINS = 256;           // bins of the start / count directory (setup_kernel<NW>: meshes of more than 16 384 faces)
-constexpr int MAX_BINS_MASKED = 1024;   // bins of the masked directory (setup_kernel_v2): 32-pixel bins = raster tiles up to 1024 x 1024
+#ifndef DIRT_MASKED_BINS
+#define DIRT_MASKED_BINS 1024
+#endif
+constexpr int MAX_BINS_MASKED = DIRT_MASKED_BINS;   // bins of the masked directory (setup_kernel_v2): 32-pixel bins = raster tiles up to 1024 x 1024
 
 // Coarse binning grid: square bins of (1 << shift) pixels, shift >= 5, bins_x * bins_y <= big (MAX_BINS or MAX_BINS_MASKED);
 // `big`: the row of the directory that holds the "big" pseudo-bin (faces touching too many bins), which every tile reads.

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
     const FaceRec* __restrict__ recs = p.recs + (size_t)ib * p.F;
     const int bin = (tr0 >> p.grid.shift) * p.grid.bins_x + (tx0 >> p.grid.shift);
     // rows `bin` and "big" of the bin x chunk directory: the 2 * nchunk runs (chunk, bin) then (chunk, big)
-    const BinCell* __restrict__ cells = p.cells + (size_t)ib * p.nchunk * (size_t)(p.grid.big + 1);
+    const BinCell* __restrict__ cells = p.cells + (size_t)ib * p.nchunk * (size_t)(p.masked ? p.grid.cell_chunk_stride : p.grid.big + 1);
     const BinEntry* __restrict__ scene_entries = p.entries + (size_t)ib * p.nchunk * (5 * (size_t)p.chunk_faces);
     const int nruns = 2 * p.nchunk;  // <= 512: two per thread
     // (masked directory -- chunks of 64 faces, setup_kernel_masked --: a cell is the mask of the chunk's faces in the bin, and
@@ -696,7 +696,7 @@ BinGrid make_bin_grid(int H, int W, int nchunk, bool masked)
     const int max_bins = masked ? MAX_BINS_MASKED : MAX_BINS;
     g.big = max_bins;
     g.cell_bin_stride = masked ? 1 : nchunk;
-    g.cell_chunk_stride = masked ? max_bins + 1 : 1;
+    g.cell_chunk_stride = masked ? ((max_bins + 2) & ~1) : 1;   // (even: a chunk's row starts at a 16-byte boundary)
     g.shift = 5;  // bins of >= 32 pixels: a raster tile (32 or 16 pixels) never straddles two bins
     while (((W + (1 << g.shift) - 1) >> g.shift) * ((H + (1 << g.shift) - 1) >> g.shift) > max_bins) ++g.shift;
     g.bins_x = (W + (1 << g.shift) - 1) >> g.shift;

@@ -31,4 +31,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_K5 -o trace -
 python tools/measure_traffic.py K3 K3-256 K5 > $OUT/traffic.log 2>&1
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 timeout 300 python tools/soak.py 10000 > $OUT/soak.log 2>&1
-ls -R $OUT | head -60
+# round 6 extras: the texture kernels, the deferred step's kernel list, per-wave traces of the forward kernels and of the
+# streaming gradient kernel (tracing build), the driver's own command three times, a fuzz sweep on this very build
+timeout 300 python tools/bench_texture.py $OUT/texture.json > $OUT/texture.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_deferred_K5 -o trace -- python tools/prof_deferred.py K5 5 > /dev/null 2>&1
+timeout 300 python tools/bench_deferred.py K5 10 > $OUT/bench_K5_deferred.json 2>> $OUT/bench.log
+if [ -f tools/_bin/libdirt_hip_trace.so ]; then
+  { DIRT_AMD_LIBRARY=$PWD/tools/_bin/libdirt_hip_trace.so timeout 300 python tools/trace_forward.py K3
+    DIRT_AMD_LIBRARY=$PWD/tools/_bin/libdirt_hip_trace.so timeout 300 python tools/trace_stream.py K3
+    DIRT_AMD_LIBRARY=$PWD/tools/_bin/libdirt_hip_trace.so timeout 300 python tools/trace_grad.py K3 | head -24; } > $OUT/traces.log 2>&1
+fi
+for i in 1 2 3; do python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --traffic off 2>/dev/null | grep '^{' > $OUT/bench_driver_cmd_$i.json; done
+timeout 300 python tools/step_ramp2.py 20 > $OUT/step_ramp.log 2>&1
+{ timeout 500 python tests/fuzz_parity.py 400 601; timeout 300 python tests/fuzz_parity.py 240 602 hostile; timeout 200 python tools/check_stream.py 150 603; } > $OUT/fuzz.log 2>&1
+ls -R $OUT | head -80

@@ -43,9 +43,9 @@ def kernel_key(name):
         return 'grad_kernel'
     if 'setup_kernel' in name:
         return 'setup_kernel'
-    if 'raster_kernel<0' in name:
+    if 'raster_kernel<0' in name or 'raster_kernel_v2<0' in name:
         return 'raster_kernel<shade>'
-    if 'raster_kernel<1' in name:
+    if 'raster_kernel<1' in name or 'raster_kernel_v2<1' in name:
         return 'raster_kernel<visibility>'
     if 'zero_kernel' in name:
         return 'zero_kernel'

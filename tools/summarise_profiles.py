@@ -23,11 +23,11 @@ def slot(kernel):
     """rocprofv3 kernel name -> the library's profiling slot (dirt_profile_name), whatever the tile-shape template."""
     if kernel.startswith('grad_kernel'):
         return 'grad_kernel'
-    if kernel.startswith('raster_kernel<0'):
+    if kernel.startswith('raster_kernel<0') or kernel.startswith('raster_kernel_v2<0'):
         return 'raster_kernel<shade>'
     if kernel.startswith('setup_kernel'):
         return 'setup_kernel'
-    if kernel.startswith('raster_kernel<1'):
+    if kernel.startswith('raster_kernel<1') or kernel.startswith('raster_kernel_v2<1'):
         return 'raster_kernel<visibility>'
     return kernel
 
@@ -70,9 +70,24 @@ def main():
     t = os.path.join(src, 'pmc_traffic.json')
     if os.path.exists(t):
         shutil.copy(t, os.path.join(dst, 'pmc_traffic.json'))
-    for name in ('soak.log', 'traffic.log'):
+    for name in ('soak.log', 'traffic.log', 'traces.log', 'fuzz.log', 'step_ramp.log', 'texture.log'):
         if os.path.exists(os.path.join(src, name)):
-            shutil.copy(os.path.join(src, name), os.path.join(dst, '%s_%s' % (tag, name.replace('.log', '.txt'))))
+            text = open(os.path.join(src, name)).read().replace('/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n', '')
+            open(os.path.join(dst, '%s_%s' % (tag, name.replace('.log', '.txt'))), 'w').write(text)
+    if os.path.exists(os.path.join(src, 'texture.json')):
+        shutil.copy(os.path.join(src, 'texture.json'), os.path.join(dst, tag + '_texture.json'))
+    stats = os.path.join(src, 'trace_deferred_K5', 'trace_kernel_stats.csv')
+    if os.path.exists(stats):
+        shutil.copy(stats, os.path.join(dst, tag + '_kernel_stats_K5_deferred.csv'))
+    drv = []
+    for i in (1, 2, 3):
+        f = os.path.join(src, 'bench_driver_cmd_%d.json' % i)
+        if os.path.exists(f) and open(f).read().strip():
+            drv.append(json.loads(open(f).read().strip().splitlines()[-1]))
+    if drv:
+        json.dump({'command': 'python bench.py --gpus 1 --steps 20 --warmup 5 (three runs on one box; --no-cpu-baseline --traffic off)',
+                   'ms_per_step': [d['ms_per_step'] for d in drv], 'ms_per_step_events_median': [d['ms_per_step_events_median'] for d in drv],
+                   'value': [d['value'] for d in drv]}, open(os.path.join(dst, tag + '_bench_driver_command.json'), 'w'), indent=1)
     print(open(os.path.join(dst, tag + '_kernel_stats.csv')).read())
 
 
