@@ -90,10 +90,12 @@ def load():
     lib.dirt_texture_sample_forward.restype = i
     lib.dirt_texture_sample_backward.argtypes = [fp, fp, fp, fp, fp, ll, i, i, i, i, i, u, vp]
     lib.dirt_texture_sample_backward.restype = i
-    lib.dirt_texture_sample_backward_image.argtypes = [fp, fp, fp, fp, fp, ll, ll, i, i, i, i, i, u, vp]
-    lib.dirt_texture_sample_backward_image.restype = i
+    override = bool(os.environ.get('DIRT_AMD_LIBRARY'))   # an A/B build of another round (tools/): older ABIs are let through
+    if hasattr(lib, 'dirt_texture_sample_backward_image') or not override:
+        lib.dirt_texture_sample_backward_image.argtypes = [fp, fp, fp, fp, fp, ll, ll, i, i, i, i, i, u, vp]
+        lib.dirt_texture_sample_backward_image.restype = i
     lib.dirt_texture_last_error.restype = ctypes.c_char_p
-    if lib.dirt_abi_version() != ABI_VERSION:
+    if lib.dirt_abi_version() != ABI_VERSION and not override:
         raise DirtLibraryError('libdirt_hip.so ABI %d != expected %d' % (lib.dirt_abi_version(), ABI_VERSION))
     _lib = lib
     return lib

@@ -380,28 +380,9 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
                     const uint32_t rowbits = (bx0 == 0 ? 1u : 0u) | (bx1 == 1 ? 2u : 0u);
                     mym4 = (by0 == 0 ? rowbits : 0u) | (by1 == 1 ? rowbits << 2 : 0u);
 #ifndef DIRT_NO_BLOCK_CULL
-                    // ... minus the blocks the TRIANGLE misses although its box touches them (about every third): an edge function is
-                    // linear, so its largest value over a block's 8 x 8 samples is at a corner sample; if that is below -bound -- the
-                    // float32 form's certified error, so the exact value is negative too -- no sample of the block is inside that
-                    // edge.  One lane per candidate, 64 candidates at once: ~60 instructions that save whole passes of the serial loop
-                    // below.  (NaN coefficients or bound: no comparison holds, nothing is culled.)
-                    const TileRec& t = s_rec[idx];
-                    const float nb = -t.bound;
-#pragma unroll
-                    for (int by = 0; by < 2; ++by) {
-                        const float dy_hi = (float)((int)box.r_min - (ry0 + 8 * by)), dy_lo = dy_hi - 7.f;     // dy = r_min - r over the block's rows
-#pragma unroll
-                        for (int bx = 0; bx < 2; ++bx) {
-                            const float dx_lo = (float)(rx0 + 8 * bx - (int)box.i_min), dx_hi = dx_lo + 7.f;   // dx = x - i_min over the block's columns
-                            bool out = false;
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                const float e = fmaf(t.a[k], t.a[k] > 0.f ? dx_hi : dx_lo, fmaf(t.b[k], t.b[k] > 0.f ? dy_hi : dy_lo, t.c[k]));
-                                out |= e < nb;
-                            }
-                            if (out) mym4 &= ~(1u << (2 * by + bx));
-                        }
-                    }
+                    // ... minus the blocks the TRIANGLE misses although its box touches them (cull_blocks, dirt_raster_common.h;
+                    // face-local record: offsets from the top-left sample of the face's box)
+                    mym4 = cull_blocks<NB>(s_rec[idx], mym4, (float)(rx0 - (int)box.i_min), (float)((int)box.r_min - ry0));
 #endif
                 }
             }

@@ -440,6 +440,10 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
 #pragma unroll
                 for (int by = 0; by < NB; ++by)
                     mym4 |= ((mk >> ((NB * wy + by) * BT + NB * wx)) & ((1u << NB) - 1u)) << (NB * by);
+#ifndef DIRT_NO_BLOCK_CULL
+                // ... minus the blocks the triangle itself misses (tile-local record: offsets from the tile's top-left sample)
+                if (mym4) mym4 = cull_blocks<NB>(s_rec[lane], mym4, (float)(8 * NB * wx), -(float)(8 * NB * wy));
+#endif
             }
             unsigned long long m = __builtin_amdgcn_ballot_w64(mym4 != 0);
             if (m) {

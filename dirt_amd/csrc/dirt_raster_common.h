@@ -96,6 +96,34 @@ __device__ __forceinline__ void make_local_rec(const FaceRec& rec, int face, con
     out->flags = flags; out->face = face;
 }
 
+// Which of a wave's NB x NB blocks (bits NB * by + bx of `m4`) a candidate's TRIANGLE can touch, given the blocks its box
+// touches: an edge function is linear, so its largest value over a block's 8 x 8 samples is at a corner sample; where that is
+// below -bound -- the float32 form's certified error, so the exact value is negative too -- no sample of the block is inside
+// that edge.  (dx_lo, dy_hi): the record's offsets (x - origin, origin row - r) of the top-left sample of block (0, 0).  One lane per
+// candidate; ~15 instructions per block that save whole passes of the serial coverage loop (round 6: about every third
+// block a box touches).  NaN coefficients or bound: no comparison holds, nothing is culled.
+template <int NB>
+__device__ __forceinline__ uint32_t cull_blocks(const TileRec& t, uint32_t m4, float dx_lo0, float dy_hi0)
+{
+    const float nb = -t.bound;
+#pragma unroll
+    for (int by = 0; by < NB; ++by) {
+        const float dy_hi = dy_hi0 - 8.f * (float)by, dy_lo = dy_hi - 7.f;
+#pragma unroll
+        for (int bx = 0; bx < NB; ++bx) {
+            const float dx_lo = dx_lo0 + 8.f * (float)bx, dx_hi = dx_lo + 7.f;
+            bool out = false;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float e = fmaf(t.a[k], t.a[k] > 0.f ? dx_hi : dx_lo, fmaf(t.b[k], t.b[k] > 0.f ? dy_hi : dy_lo, t.c[k]));
+                out |= e < nb;
+            }
+            if (out) m4 &= ~(1u << (NB * by + bx));
+        }
+    }
+    return m4;
+}
+
 // The specification's f64 coverage test for the samples the float filter cannot decide.  Rare; kept out of
 // line (and reading the FaceRec from global memory) so that nothing of it is speculated into the main loop.
 static __device__ __noinline__ bool covered_exact(const FaceRec* __restrict__ rec, double px, double py)
