@@ -27,9 +27,20 @@ def main():
     def shader(g):
         return g[..., :3] * g[..., 3:4]
 
+    def shader_split(g):
+        # the same arithmetic with ONE split: torch's backward of k slices of the G-buffer is k zero-filled G-buffer-sized
+        # gradients added up; the backward of a split is a single concatenation
+        rgb, k, _ = g.split([3, 1, C - 4], dim=-1)
+        return rgb * k
+
     def step_shared():
         bg.grad = v.grad = a.grad = None   # (as an optimiser's zero_grad(set_to_none=True): no 268 MB accumulate-into-.grad kernel)
         px = ops.rasterise_deferred(bg, v, a, f, shader)
+        px.backward(d)
+
+    def step_shared_split():
+        bg.grad = v.grad = a.grad = None
+        px = ops.rasterise_deferred(bg, v, a, f, shader_split)
         px.backward(d)
 
     def step_rerender():  # the same arithmetic with a fresh set-up + visibility render in each of the three calls
@@ -53,8 +64,10 @@ def main():
     out = {'config': config, 'steps': steps,
            'legs': 'shared_state: dirt_amd.rasterise_deferred(...).backward() (autograd engine: ~0.1 ms of host time per step); '
                    'shared_state_raw / rerender: the same arithmetic as raw op calls, with the forward state shared / with a fresh '
-                   'set-up + visibility render in each gradient call'}
-    for name, fn in (('shared_state', step_shared), ('shared_state_raw', step_shared_raw), ('rerender', step_rerender)):
+                   'set-up + visibility render in each gradient call; shared_state_split_shader: shared_state with the shader '
+                   'written with one split of the G-buffer instead of two slices (torch autograd cost of the shader, not of the path)'}
+    for name, fn in (('shared_state', step_shared), ('shared_state_split_shader', step_shared_split), ('shared_state_raw', step_shared_raw),
+                     ('rerender', step_rerender)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
