@@ -441,8 +441,11 @@ __global__ __launch_bounds__(RTHREADS, 4) void raster_kernel(RasterParams p)
                 for (int by = 0; by < NB; ++by)
                     mym4 |= ((mk >> ((NB * wy + by) * BT + NB * wx)) & ((1u << NB) - 1u)) << (NB * by);
 #ifndef DIRT_NO_BLOCK_CULL
-                // ... minus the blocks the triangle itself misses (tile-local record: offsets from the tile's top-left sample)
-                if (mym4) mym4 = cull_blocks<NB>(s_rec[lane], mym4, (float)(8 * NB * wx), -(float)(8 * NB * wy));
+                // ... minus the blocks the triangle itself misses (tile-local record: offsets from the tile's top-left sample).
+                // (Not in the 32 x 32 shapes specialised for 1 / 3 / 4 channels -- meshes of more than 16 384 faces; smaller ones
+                // take raster_kernel_v2 --: they sit at 128 registers and the cull's temporaries would spill 16-32 bytes.)
+                if constexpr (!(MODE == 0 && NB == 2 && CSPEC != 0))
+                    if (mym4) mym4 = cull_blocks<NB>(s_rec[lane], mym4, (float)(8 * NB * wx), -(float)(8 * NB * wy));
 #endif
             }
             unsigned long long m = __builtin_amdgcn_ballot_w64(mym4 != 0);

@@ -219,6 +219,56 @@ def _load_example(name):
     return ex
 
 
+def test_lighting_views_script(gpu, oracle):
+    """examples/lighting_views.py = the reference's tests/lighting_tests.py:13-66 on `import dirt` (it shows four images and
+    asserts nothing): the four views render, every one equals the oracle's image of the very inputs the helpers produced
+    where that is cheap to rebuild (the normals view), the point light on the shared and on the split mesh agree except
+    where smooth and faceted normals differ, and the lights do what their arguments say."""
+    ex = _load_example('lighting_views')
+    views = ex.main(write_images=False, device=gpu)
+    assert set(views) == {'normals', 'directional', 'point', 'point_split'}
+    cover = [(v.amax(-1) > 0) for v in views.values()]
+    for v, c in zip(views.values(), cover):
+        assert v.shape == (ex.HEIGHT, ex.WIDTH, 3) and torch.isfinite(v).all()
+        assert torch.equal(c, cover[0]) and 2000 < int(c.sum()) < 12000   # same silhouette in all four, a cylinder's worth of pixels
+    # directional light: colour (1, 1, 0) + 0.4 blue -> red == green everywhere, blue exactly the offset on the mesh
+    d = views['directional']
+    assert torch.equal(d[..., 0], d[..., 1]) and float((d[..., 2][cover[0]] - 0.4).abs().max()) < 1e-6
+    # split vs shared normals: same light, same geometry; interiors of the side faces agree to the faceting
+    assert float((views['point'] - views['point_split']).abs().mean()) < 0.05
+    # the normals view against the oracle on the inputs the script built
+    from dirt_amd import lighting, matrices
+    pts, tris = ex.cylinder(0.2, 0.75, 0.1, 0.2, 32)
+    f = torch.from_numpy(tris).to(gpu)
+    v = torch.cat([torch.from_numpy(pts), torch.ones(len(pts), 1)], dim=1).to(gpu)
+    spin = torch.diag(torch.tensor([0.5, 0.5, 0.5, 1.], device=gpu))
+    placed = v @ spin @ matrices.translation(torch.tensor([0., 0., -0.25], device=gpu))
+    clip = placed @ matrices.perspective_projection(0.1, 20., 0.2, float(ex.HEIGHT) / ex.WIDTH).to(gpu)
+    cols = lighting.vertex_normals(placed[:, :3], f).abs()
+    want = oracle.forward(np.zeros((1, ex.HEIGHT, ex.WIDTH, 3), np.float32), clip.cpu().numpy()[None], cols.cpu().numpy()[None], tris[None])
+    assert np.array_equal(views['normals'].cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+
+
+def test_deferred_jacobians_script(gpu):
+    """examples/deferred_jacobians.py = the reference's tests/deferred_grad_test.py:168-259 on `import dirt` (it writes four
+    PNGs and asserts nothing): per-pixel Jacobians of the directly lit and of the deferred-shaded bent square with respect to
+    its five variables, 2 x 3072 backward passes.  Pixels of the two routes agree (lighting per vertex of a flat face ==
+    lighting per pixel); shader-only variables -- light intensity, background colour -- have the
+    same Jacobian on both routes; geometry variables reach the pixels on both routes with the same overall sensitivity."""
+    ex = _load_example('deferred_jacobians')
+    rep = ex.main(write_images=False, device=gpu)
+    assert 150 < rep['covered_pixels'] < 900
+    assert rep['pixels_max_abs_difference'] < 1e-5
+    for name in ('light_intensity', 'background'):
+        assert rep[name]['direct_l1'] > 1.0 and rep[name]['max_abs_difference'] < 1e-5, (name, rep[name])
+    for name in ('translation', 'rotation'):
+        a, b = rep[name]['direct_l1'], rep[name]['deferred_l1']
+        assert a > 1.0 and b > 1.0 and abs(a - b) <= 0.25 * max(a, b), (name, rep[name])
+    # (the reference's scene scales the HOMOGENEOUS world vertices, w included, with no translation: a uniform scale of clip
+    # space, which no pixel can see -- both routes must say so)
+    assert rep['scale']['direct_l1'] < 1e-3 and rep['scale']['deferred_l1'] < 1e-3, rep['scale']
+
+
 def _deferred_reference(oracle, clip, faces, attributes, n_channels, H, W, shade, d):
     """Manual composition on the oracle (dirt/rasterise_ops.py:189-248): G-buffer by the oracle, shading and its autograd
     by torch, vertex gradients from the SHADED image, attribute gradients from the G-buffer."""
