@@ -224,17 +224,19 @@ static_assert(sizeof(ShadeSlot<true>) == 144 && sizeof(ShadeSlot<false>) == 96, 
 
 }  // namespace
 
-// raster_kernel_v2<MODE, CSPEC>: MODE 0 renders CSPEC = 1, 3, 4 channels (pixels, and the backward pass's state when
-// p.state_a); MODE 1 is the visibility pass (p.vis and / or the state; no colours).  32 x 32-pixel tiles, four waves, each
-// owning a 16 x 16 region = 2 x 2 blocks of 8 x 8 pixels (one pixel of every block per lane), from the coverage loop to the
-// stores: dirt_raster.hip's decomposition.
+// raster_kernel_v2<MODE, CSPEC, WAVES>: MODE 0 renders CSPEC = 1, 3, 4 channels (pixels, and the backward pass's state when
+// p.state_a); MODE 1 is the visibility pass (p.vis and / or the state; no colours).  32 x 32-pixel tiles.  WAVES = 4: each
+// wave owns a 16 x 16 region = 2 x 2 blocks of 8 x 8 pixels (one pixel of every block per lane), from the coverage loop to the
+// stores: dirt_raster.hip's decomposition.  WAVES = 8 (512 threads, <= 64 registers, eight waves per SIMD): a wave owns a
+// 16 x 8 region = 2 x 1 blocks -- for launches whose workgroups are all resident at once (one scene of 1024 x 1024): the
+// kernel then ends with its heaviest wave, and half-size waves halve that wave's serial candidate loop and its shading.
 #ifndef DIRT_V2_WAVES
 #define DIRT_V2_WAVES 4
 #endif
-template <int MODE, int CSPEC>
-__global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(RasterParams p)
+template <int MODE, int CSPEC, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 8 : DIRT_V2_WAVES) void raster_kernel_v2(RasterParams p)
 {
-    constexpr int NB = 2, TILE = 32, PPL = 4;
+    constexpr int NB = 2, NBY = WAVES == 8 ? 1 : 2, TILE = 32, PPL = NB * NBY, THREADS = 64 * WAVES, RH = 8 * NBY;
     constexpr bool COLOURS = MODE == 0;
     constexpr int SPARTS = COLOURS ? 9 : 6;
     using Slot = ShadeSlot<COLOURS>;
@@ -242,7 +244,6 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
     __shared__ __align__(16) Slot s_shade[V2_CAP];
     __shared__ int32_t s_face[V2_CAP];
     __shared__ uint32_t s_count;
-
     FTRACE_DECL();
     FMARK();  // 0 start
 #ifdef DIRT_TRACE
@@ -273,16 +274,15 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
         m_big = ((unsigned long long)b.count << 32) | b.start;
     }
 
-    // this wave's region (blocks 2 wx .., 2 wy .. of the tile) and this lane's 2 x 2 pixels
+    // this wave's region (16 pixels wide, RH tall) and this lane's NB x NBY pixels, one of every 8 x 8 block
     const int wx = wave & 1, wy = wave >> 1;
     const int x0 = tx0 + wx * 16 + (lane & 7);
-    const int r0 = tr0 + wy * 16 + (lane >> 3);
-    double px[NB], py[NB];
+    const int r0 = tr0 + wy * RH + (lane >> 3);
+    double px[NB], py[NBY];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        px[k] = (double)(x0 + 8 * k) + 0.5;
-        py[k] = (double)(p.H - 1 - (r0 + 8 * k)) + 0.5;
-    }
+    for (int k = 0; k < NB; ++k) px[k] = (double)(x0 + 8 * k) + 0.5;
+#pragma unroll
+    for (int k = 0; k < NBY; ++k) py[k] = (double)(p.H - 1 - (r0 + 8 * k)) + 0.5;
     unsigned long long best[PPL];   // (z24 << 32 | face) of the front-most fragment so far
     int cbest[PPL];                 // the winner's slot (its shading data is in LDS when < V2_CAP and lds_records)
 #pragma unroll
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
     // side job: this workgroup's share of the buffers the launch clears (the backward pass's gradient accumulators)
     if ((p.zero_b_bytes | p.zero_c_bytes) != 0) {
         const unsigned gwg = blockIdx.y * gridDim.x + blockIdx.x;
-        if (p.zero_b_bytes) zero_share(p.zero_b, p.zero_b_bytes, p.zero_b_per, gwg, tid);
-        if (p.zero_c_bytes) zero_share(p.zero_c, p.zero_c_bytes, p.zero_c_per, gwg, tid);
+        if (p.zero_b_bytes) zero_share<THREADS>(p.zero_b, p.zero_b_bytes, p.zero_b_per, gwg, tid);
+        if (p.zero_c_bytes) zero_share<THREADS>(p.zero_c, p.zero_c_bytes, p.zero_c_per, gwg, tid);
     }
     const uint32_t lds_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(&s_rec[0]));
     const uint32_t lds_shade = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(&s_shade[0]));
@@ -338,12 +338,16 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
         if (round != 0) lds_records = false;
 
         // ---- trip 2: the candidates' coverage records, 16-byte piece idx = 5 slot + part, lane-linear into s_rec ----
+        // (the pieces' slot / part are functions of the thread index alone; an opaque copy of it keeps the compiler from hoisting
+        // a dozen of them out of the round loop, where they would be live -- in the eight-wave shape: spilled -- across everything)
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
 #pragma unroll
-        for (int k = 0; k < (5 * V2_CAP + RTHREADS - 1) / RTHREADS; ++k) {
-            const int idx = tid + RTHREADS * k;
+        for (int k = 0; k < (5 * V2_CAP + THREADS - 1) / THREADS; ++k) {
+            const int idx = tid_o + THREADS * k;
             if (idx < 5 * n) {
                 const int slot = idx / 5, part = idx - 5 * slot;
-                glds16(lrecs, (uint32_t)s_face[slot] * (uint32_t)sizeof(TileRec) + 16u * (uint32_t)part, lds_rec + 1024u * (uint32_t)(wave + 4 * k));
+                glds16(lrecs, (uint32_t)s_face[slot] * (uint32_t)sizeof(TileRec) + 16u * (uint32_t)part, lds_rec + 1024u * (uint32_t)(wave + WAVES * k));
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -354,12 +358,12 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
         //      part: the six pieces of the set-up record's head, then the three colours ----
         if (round == 0) {
 #pragma unroll
-            for (int k = 0; k < (SPARTS * V2_CAP + RTHREADS - 1) / RTHREADS; ++k) {
-                const int idx = tid + RTHREADS * k;
+            for (int k = 0; k < (SPARTS * V2_CAP + THREADS - 1) / THREADS; ++k) {
+                const int idx = tid_o + THREADS * k;
                 if (idx < SPARTS * n) {
                     const int slot = idx / SPARTS, part = idx - SPARTS * slot;
                     const uint32_t face = (uint32_t)s_face[slot];
-                    const uint32_t dst = lds_shade + 1024u * (uint32_t)(wave + 4 * k);
+                    const uint32_t dst = lds_shade + 1024u * (uint32_t)(wave + WAVES * k);
                     if (part < 6) glds16(recs, face * (uint32_t)sizeof(FaceRec) + 16u * (uint32_t)part, dst);
                     if (COLOURS && part >= 6) glds16(crecs, face * 48u + 16u * (uint32_t)(part - 6), dst);
                 }
@@ -373,16 +377,16 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
             if (idx < n) {
                 const FaceBox box = s_rec[idx].box;
                 // the wave's blocks (bx, by) the box touches, as bits 2 by + bx
-                const int rx0 = tx0 + 16 * wx, ry0 = tr0 + 16 * wy;
+                const int rx0 = tx0 + 16 * wx, ry0 = tr0 + RH * wy;
                 const int bx0 = max(box.i_min - rx0, 0) >> 3, bx1 = min(box.i_max - rx0, 15) >> 3;
-                const int by0 = max(box.r_min - ry0, 0) >> 3, by1 = min(box.r_max - ry0, 15) >> 3;
-                if (box.i_max >= rx0 && box.i_min <= rx0 + 15 && box.r_max >= ry0 && box.r_min <= ry0 + 15) {
+                const int by0 = max(box.r_min - ry0, 0) >> 3, by1 = min(box.r_max - ry0, RH - 1) >> 3;
+                if (box.i_max >= rx0 && box.i_min <= rx0 + 15 && box.r_max >= ry0 && box.r_min <= ry0 + RH - 1) {
                     const uint32_t rowbits = (bx0 == 0 ? 1u : 0u) | (bx1 == 1 ? 2u : 0u);
-                    mym4 = (by0 == 0 ? rowbits : 0u) | (by1 == 1 ? rowbits << 2 : 0u);
+                    mym4 = (by0 == 0 ? rowbits : 0u) | (NBY == 2 && by1 == 1 ? rowbits << 2 : 0u);
 #ifndef DIRT_NO_BLOCK_CULL
                     // ... minus the blocks the TRIANGLE misses although its box touches them (cull_blocks, dirt_raster_common.h;
                     // face-local record: offsets from the top-left sample of the face's box)
-                    mym4 = cull_blocks<NB>(s_rec[idx], mym4, (float)(rx0 - (int)box.i_min), (float)((int)box.r_min - ry0));
+                    mym4 = cull_blocks<NB, NBY>(s_rec[idx], mym4, (float)(rx0 - (int)box.i_min), (float)((int)box.r_min - ry0));
 #endif
                 }
             }
@@ -390,13 +394,12 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
             auto visit = [&](const TileRec& t, int k) {
                 const uint32_t m4 = (uint32_t)__builtin_amdgcn_readlane((int)mym4, k);
                 // sample offsets from the face's origin (the top-left pixel of its box): exact small integers
-                float dxl[NB], dyl[NB];
+                float dxl[NB], dyl[NBY];
 #pragma unroll
-                for (int q = 0; q < NB; ++q) {
-                    dxl[q] = (float)(x0 + 8 * q - (int)t.box.i_min);
-                    dyl[q] = (float)((int)t.box.r_min - (r0 + 8 * q));
-                }
-                raster_candidate<NB>(t, recs, round == 0 ? cb + k : V2_CAP, m4, dxl, dyl, px, py, best, cbest);
+                for (int q = 0; q < NB; ++q) dxl[q] = (float)(x0 + 8 * q - (int)t.box.i_min);
+#pragma unroll
+                for (int q = 0; q < NBY; ++q) dyl[q] = (float)((int)t.box.r_min - (r0 + 8 * q));
+                raster_candidate<NB, NBY>(t, recs, round == 0 ? cb + k : V2_CAP, m4, dxl, dyl, px, py, best, cbest);
 #ifdef DIRT_TRACE
                 ++tr_cand;
 #endif
@@ -423,26 +426,34 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
     for (int k = 0; k < PPL; ++k) fbest[k] = (uint32_t)(best[k] >> 32) != Z24_CLEAR ? (int32_t)(uint32_t)best[k] : -1;
 
     // ---- shade ----
-    // this lane's pixels: background where nothing is visible (requested now, used last)
-    bool inside[PPL];
-    size_t pix[PPL];
-    float4 bgv[PPL];
-#pragma unroll
-    for (int k = 0; k < PPL; ++k) {
+    // Per pixel: barycentrics of the winner (csrc/shaders.cpp:52-57,74) from its record in LDS -- or, for candidates of later
+    // rounds, in memory --, the backward pass's state, the interpolated colours, the HWC pixel; background where nothing is
+    // visible.  (WAVES = 4 requests the background of all its pixels first and uses it last; the eight-wave shape has 64
+    // registers and twice the waves to hide a load behind: it fetches per pixel.  Bringing it in by LDS-DMA before the
+    // candidates instead was measured: K3 raster 20.7 against 18.3 us -- 16 MB of requests in front of the directory reads.)
+    constexpr bool BG_FIRST = WAVES != 8;
+    const float* __restrict__ cols = COLOURS ? p.vertex_colors + (size_t)ib * p.V * C : nullptr;
+    auto pixel_index = [&](int k, bool& inside) {
         const int x = x0 + 8 * (k % NB), r = r0 + 8 * (k / NB);
-        inside[k] = x < p.W && r < p.H;
-        pix[k] = ((size_t)ib * p.H + min(r, p.H - 1)) * p.W + min(x, p.W - 1);
-        bgv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE == 0 && inside[k] && fbest[k] < 0) {
-            const float* __restrict__ bg = p.background + pix[k] * C;
-            if (CSPEC == 4) bgv[k] = *reinterpret_cast<const float4*>(bg);
-            else if (CSPEC == 3) bgv[k] = make_float4(bg[0], bg[1], bg[2], 0.f);
-            else bgv[k] = make_float4(bg[0], 0.f, 0.f, 0.f);
+        inside = x < p.W && r < p.H;
+        return ((size_t)ib * p.H + min(r, p.H - 1)) * p.W + min(x, p.W - 1);
+    };
+    auto background_at = [&](size_t pix) {
+        const float* __restrict__ bg = p.background + pix * C;
+        if (CSPEC == 4) return *reinterpret_cast<const float4*>(bg);
+        else if (CSPEC == 3) return make_float4(bg[0], bg[1], bg[2], 0.f);
+        else return make_float4(bg[0], 0.f, 0.f, 0.f);
+    };
+    float4 bgv[BG_FIRST ? PPL : 1];
+    if constexpr (BG_FIRST) {
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+            bool inside;
+            const size_t pix = pixel_index(k, inside);
+            bgv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == 0 && inside && fbest[k] < 0) bgv[k] = background_at(pix);
         }
     }
-    // Per pixel: barycentrics of the winner (csrc/shaders.cpp:52-57,74) from its record in LDS -- or, for candidates of later
-    // rounds, in memory --, the backward pass's state, the interpolated colours, the HWC pixel.
-    const float* __restrict__ cols = COLOURS ? p.vertex_colors + (size_t)ib * p.V * C : nullptr;
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
         const int32_t f = fbest[k];
@@ -454,36 +465,43 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
         for (int i = 0; i < 9; ++i) cf[i] = s_shade[ci].coef[i];
         uint32_t flags = s_shade[ci].flags;
         double inv_det = s_shade[ci].inv_det;
-        float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0, u2 = u0;
-        if constexpr (COLOURS) { u0 = s_shade[ci].col[0]; u1 = s_shade[ci].col[1]; u2 = s_shade[ci].col[2]; }
-        if (__builtin_amdgcn_ballot_w64(has && !from_lds) != 0ull) {
-            if (has && !from_lds) {
-                const FaceRec* __restrict__ rec = recs + f;
+        const bool from_mem = has && !from_lds;
+        const bool any_from_mem = __builtin_amdgcn_ballot_w64(from_mem) != 0ull;   // (wave-uniform; rare: tiles of more than V2_CAP candidates)
+        if (any_from_mem && from_mem) {
+            const FaceRec* __restrict__ rec = recs + f;
 #pragma unroll
-                for (int i = 0; i < 9; ++i) cf[i] = rec->coef[i];
-                flags = rec->flags; inv_det = rec->inv_det;
-                if constexpr (COLOURS) {
-                    const float* __restrict__ c0 = cols + (size_t)rec->vid[0] * C;
-                    const float* __restrict__ c1 = cols + (size_t)rec->vid[1] * C;
-                    const float* __restrict__ c2 = cols + (size_t)rec->vid[2] * C;
-                    if (CSPEC == 4) { u0 = *reinterpret_cast<const float4*>(c0); u1 = *reinterpret_cast<const float4*>(c1); u2 = *reinterpret_cast<const float4*>(c2); }
-                    else if (CSPEC == 3) { u0 = make_float4(c0[0], c0[1], c0[2], 0.f); u1 = make_float4(c1[0], c1[1], c1[2], 0.f); u2 = make_float4(c2[0], c2[1], c2[2], 0.f); }
-                    else { u0 = make_float4(c0[0], 0.f, 0.f, 0.f); u1 = make_float4(c1[0], 0.f, 0.f, 0.f); u2 = make_float4(c2[0], 0.f, 0.f, 0.f); }
-                }
-            }
+            for (int i = 0; i < 9; ++i) cf[i] = rec->coef[i];
+            flags = rec->flags; inv_det = rec->inv_det;
         }
         double Fk[3];
         edge_eval(cf, (double)(x0 + 8 * (k % NB)) + 0.5, (double)(p.H - 1 - (r0 + 8 * (k / NB))) + 0.5, Fk);
         float b[3], cw;
         bary_eval(Fk, flags, inv_det, b, cw);
         const float b0 = b[0], b1 = b[1], b2 = b[2];
-        if (!inside[k]) continue;
+        bool inside;
+        const size_t pix = pixel_index(k, inside);
+        if (!inside) continue;
         // the backward pass's state and the visibility export
-        if (p.vis) p.vis[pix[k]] = f;
-        if (p.state_a) store_state(p, pix[k], has, b0, b1, b2, cw, f);
+        if (p.vis) p.vis[pix] = f;
+        if (p.state_a) store_state(p, pix, has, b0, b1, b2, cw, f);
         if (MODE != 0) continue;
-        float* __restrict__ out = p.pixels + pix[k] * C;
-        float4 o = bgv[k];   // pixels start as the background: csrc/rasterise_egl.cpp:348-356
+        float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0, u2 = u0;
+        if constexpr (COLOURS) { u0 = s_shade[ci].col[0]; u1 = s_shade[ci].col[1]; u2 = s_shade[ci].col[2]; }
+        if (any_from_mem && from_mem) {
+            if constexpr (COLOURS) {
+                const FaceRec* __restrict__ rec = recs + f;
+                const float* __restrict__ c0 = cols + (size_t)rec->vid[0] * C;
+                const float* __restrict__ c1 = cols + (size_t)rec->vid[1] * C;
+                const float* __restrict__ c2 = cols + (size_t)rec->vid[2] * C;
+                if (CSPEC == 4) { u0 = *reinterpret_cast<const float4*>(c0); u1 = *reinterpret_cast<const float4*>(c1); u2 = *reinterpret_cast<const float4*>(c2); }
+                else if (CSPEC == 3) { u0 = make_float4(c0[0], c0[1], c0[2], 0.f); u1 = make_float4(c1[0], c1[1], c1[2], 0.f); u2 = make_float4(c2[0], c2[1], c2[2], 0.f); }
+                else { u0 = make_float4(c0[0], 0.f, 0.f, 0.f); u1 = make_float4(c1[0], 0.f, 0.f, 0.f); u2 = make_float4(c2[0], 0.f, 0.f, 0.f); }
+            }
+        }
+        float* __restrict__ out = p.pixels + pix * C;
+        float4 o;   // pixels start as the background: csrc/rasterise_egl.cpp:348-356
+        if constexpr (BG_FIRST) o = bgv[k];
+        else o = has ? make_float4(0.f, 0.f, 0.f, 0.f) : background_at(pix);
         if (has) {
             o.x = fmaf(b2, u2.x, fmaf(b1, u1.x, b0 * u0.x));
             if (CSPEC >= 3) { o.y = fmaf(b2, u2.y, fmaf(b1, u1.y, b0 * u0.y)); o.z = fmaf(b2, u2.z, fmaf(b1, u1.z, b0 * u0.z)); }
@@ -496,7 +514,7 @@ __global__ __launch_bounds__(RTHREADS, DIRT_V2_WAVES) void raster_kernel_v2(Rast
     FMARK();  // 9 shaded, stores issued
 #ifdef DIRT_TRACE
     if (lane == 0 && g_trace_fwd_raster) {
-        long long* o = g_trace_fwd_raster + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16;
+        long long* o = g_trace_fwd_raster + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 16;
         for (int i = 0; i < 12; ++i) o[i] = i < tr_n ? tr_t[i] : 0;
         o[12] = tr_wall0; o[13] = (long long)wall_clock64() - tr_wall0; o[14] = blockIdx.x; o[15] = tr_cand;
     }
@@ -529,7 +547,17 @@ hipError_t launch_raster_v2(const RasterParams& p_in, int B, bool visibility_onl
         p.zero_b_per = (unsigned)((p.zero_b_bytes / 16 + nwg - 1) / nwg);
         p.zero_c_per = (unsigned)((p.zero_c_bytes / 16 + nwg - 1) / nwg);
     }
+    // half-size waves (eight per workgroup) where every workgroup of the launch is resident at once -- at most four 512-thread
+    // workgroups per compute unit --: such a launch ends with its heaviest wave (profiles/EXPERIMENTS.md round 6)
+#ifdef DIRT_V2_NO_W8
+    const bool w8 = false;
+#else
+    const bool w8 = (size_t)grid.x * grid.y <= 1024 && !visibility_only && !(p.flags & DIRT_FLAG_TILES_LARGE);
+#endif
     if (visibility_only) hipLaunchKernelGGL((raster_kernel_v2<1, 4>), grid, dim3(RTHREADS), 0, stream, p);
+    else if (w8 && p.C == 4) hipLaunchKernelGGL((raster_kernel_v2<0, 4, 8>), grid, dim3(512), 0, stream, p);
+    else if (w8 && p.C == 3) hipLaunchKernelGGL((raster_kernel_v2<0, 3, 8>), grid, dim3(512), 0, stream, p);
+    else if (w8) hipLaunchKernelGGL((raster_kernel_v2<0, 1, 8>), grid, dim3(512), 0, stream, p);
     else if (p.C == 4) hipLaunchKernelGGL((raster_kernel_v2<0, 4>), grid, dim3(RTHREADS), 0, stream, p);
     else if (p.C == 3) hipLaunchKernelGGL((raster_kernel_v2<0, 3>), grid, dim3(RTHREADS), 0, stream, p);
     else hipLaunchKernelGGL((raster_kernel_v2<0, 1>), grid, dim3(RTHREADS), 0, stream, p);

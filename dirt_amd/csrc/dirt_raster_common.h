@@ -102,12 +102,12 @@ __device__ __forceinline__ void make_local_rec(const FaceRec& rec, int face, con
 // that edge.  (dx_lo, dy_hi): the record's offsets (x - origin, origin row - r) of the top-left sample of block (0, 0).  One lane per
 // candidate; ~15 instructions per block that save whole passes of the serial coverage loop (round 6: about every third
 // block a box touches).  NaN coefficients or bound: no comparison holds, nothing is culled.
-template <int NB>
+template <int NB, int NBY = NB>
 __device__ __forceinline__ uint32_t cull_blocks(const TileRec& t, uint32_t m4, float dx_lo0, float dy_hi0)
 {
     const float nb = -t.bound;
 #pragma unroll
-    for (int by = 0; by < NB; ++by) {
+    for (int by = 0; by < NBY; ++by) {
         const float dy_hi = dy_hi0 - 8.f * (float)by, dy_lo = dy_hi - 7.f;
 #pragma unroll
         for (int bx = 0; bx < NB; ++bx) {
@@ -147,13 +147,13 @@ static __device__ __noinline__ bool covered_exact(const FaceRec* __restrict__ re
 //             in index order does (csrc/rasterise_egl.cpp:373-379): both as one unsigned compare of the 64-bit key
 //             (z24 << 32 | face).  The stored key starts as (Z24_CLEAR << 32 | 0): no fragment at the cleared depth is
 //             ever less.  Bitwise, not short-circuit, operators: one predicated update instead of nested divergent branches.
-template <int NB>
+template <int NB, int NBY = NB>
 __device__ __forceinline__ void raster_candidate(const TileRec& t, const FaceRec* __restrict__ recs, int ci, uint32_t m4, const float* dx,
                                                  const float* dy, const double* px, const double* py, unsigned long long* best,
                                                  int* cbest)
 {
 #pragma unroll
-    for (int by = 0; by < NB; ++by) {
+    for (int by = 0; by < NBY; ++by) {
         if (!((m4 >> (NB * by)) & ((1u << NB) - 1u))) continue;   // wave-uniform: the candidate's box misses this block row
         float trow[3];
         trow[0] = fmaf(t.b[0], dy[by], t.c[0]);
@@ -237,12 +237,13 @@ __device__ __forceinline__ void store_state(const RasterParams& p, size_t pix, b
 
 // One workgroup's share of a buffer to clear: `per` 16-byte units (the buffers are 16-byte aligned: [B,V,4] floats, the
 // 256-byte aligned workspace regions), a dword tail for caller tensors whose size is not a multiple of 16.
+template <int NTHREADS = RTHREADS>
 __device__ __forceinline__ void zero_share(void* buf, size_t bytes, unsigned per, unsigned gwg, int tid)
 {
     const size_t units = bytes / 16;
     const size_t i0 = (size_t)gwg * per;
     uint4* q = reinterpret_cast<uint4*>(buf);
-    for (unsigned i = (unsigned)tid; i < per; i += RTHREADS)
+    for (unsigned i = (unsigned)tid; i < per; i += NTHREADS)
         if (i0 + i < units) q[i0 + i] = make_uint4(0u, 0u, 0u, 0u);
     if (gwg == 0 && (size_t)tid < (bytes % 16) / 4) reinterpret_cast<uint32_t*>(buf)[units * 4 + tid] = 0u;
 }

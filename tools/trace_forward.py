@@ -13,7 +13,7 @@ s = scenes.rand_scene(F, H, W, C, seed, rlo, rhi)
 dev = torch.device('cuda:0')
 t = {k: torch.from_numpy(np.ascontiguousarray(s[k]))[None].to(dev) for k in ('background', 'vertices', 'vertex_colors', 'faces')}
 bs = torch.zeros(4096 * 16, dtype=torch.int64, device=dev)
-br = torch.zeros(4 * 4096 * 4 * 16, dtype=torch.int64, device=dev)
+br = torch.zeros(4 * 4096 * 8 * 16, dtype=torch.int64, device=dev)   # (up to eight waves per workgroup)
 for it in range(4):
     if it == 3:
         lib.dirt_debug_set_trace_forward(ctypes.c_void_p(bs.data_ptr()), ctypes.c_void_p(br.data_ptr()))
