@@ -19,6 +19,9 @@ HIPCC_FLAGS = [
     '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
     '-ffp-contract=off', '-fno-fast-math', '-fhip-fp32-correctly-rounded-divide-sqrt',
     '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function',
+    # gfx950 loads the first kernel arguments into SGPRs while a wave is launched: kernels that list, before their parameter
+    # struct, the scalars their first memory trip is addressed with start that trip without a scalar load of the argument segment
+    '-mllvm', '-amdgpu-kernarg-preload-count=16',
 ]
 
 

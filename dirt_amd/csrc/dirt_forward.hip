@@ -71,23 +71,44 @@ __device__ __forceinline__ uint32_t lds_address(T* p)
 
 // ---- set-up ----------------------------------------------------------------------------------------------------------
 // CK: the channel count whose vertex colours ride along (1, 3, 4), or 0: none (the visibility / stateless backward passes).
+// One workgroup of FOUR waves per chunk of 64 faces.  The chip is almost empty while this kernel runs (157 chunks at K3) and a
+// wave's time is its instruction count (profiles/EXPERIMENTS.md): wave 0 keeps the dependent chain -- requests, the face's
+// arithmetic (one face per lane), its bits in the bin masks -- and leaves its three records in LDS; the other three waves
+// clear the masks meanwhile, and afterwards all four copy the records out as whole 16-byte runs (a lane storing its own
+// 128 + 80 + 48 bytes touches 64 lines per store instruction; the chunk's records are CONTIGUOUS in memory, so the copy is
+// linear) and store the chunk's row of the directory.  (Rounds 5-6a: one wave did everything: 8 195 clocks.)
+constexpr int STHREADS = 256;
+// (Leading scalar arguments = the fields the first trip is addressed with, PRELOADED into SGPRs at wave launch: see raster_kernel_v2.)
 template <int CK>
-__global__ __launch_bounds__(64) void setup_kernel_v2(GeomParams g)
+__global__ __launch_bounds__(STHREADS) void setup_kernel_v2(const float* __restrict__ a_vertices, const int32_t* __restrict__ a_faces,
+                                                            const float* __restrict__ a_vertex_colors, int a_shared_faces, int a_V, int a_F,
+                                                            GeomParams g_in)
 {
+    GeomParams g = g_in;
+    g.vertices = a_vertices; g.faces = a_faces; g.vertex_colors = a_vertex_colors; g.shared_faces = a_shared_faces; g.V = a_V; g.F = a_F;
     __shared__ __align__(16) unsigned long long s_mask[MAX_BINS_MASKED + 2];    // [grid.big] = big faces
-    const int ib = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
+    __shared__ __align__(16) FaceRec s_recs[64];
+    __shared__ __align__(16) TileRec s_lrecs[64];
+    __shared__ __align__(16) float4 s_crecs[CK ? 3 * 64 : 1];
+    const int ib = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     FTRACE_DECL();
     FMARK();  // 0 start
     const int nbins = g.grid.bins_x * g.grid.bins_y, big = g.grid.big;
     BinCell* __restrict__ row = g.cells + ((size_t)ib * g.nchunk + chunk) * (size_t)g.grid.cell_chunk_stride;   // chunk-major: this chunk's cells are contiguous
-    const int f = chunk * 64 + lane;
-    const bool have = f < g.F && g.V > 0;
     if (g.F == 0 || g.V <= 0) {   // (uniform) nothing to set up: an all-zero row is what the raster kernel reads
-        for (int i = lane; i <= big; i += 64) if (i < nbins || i == big) row[i] = BinCell{0u, 0u};
+        for (int i = tid; i <= big; i += STHREADS) if (i < nbins || i == big) row[i] = BinCell{0u, 0u};
         return;
     }
-    const int fs = have ? f : 0;                                   // (lanes past the last face: face 0, nothing stored)
-    const size_t n = (size_t)ib * g.F + fs;
+    const int f0 = chunk * 64;
+    const int nf = min(64, g.F - f0);            // faces of this chunk (the last one may be short)
+    const size_t n0 = (size_t)ib * g.F + f0;     // ... and their first record
+    // wave 0's registers across the first barrier
+    int32_t idx[3] = {0, 0, 0};
+    float4 vv[3], cv[3];
+    const int f = f0 + lane;
+    const bool have = wave == 0 && lane < nf;
+    const int fs = lane < nf ? f : 0;            // (lanes past the last face: face 0, nothing stored)
     const float* __restrict__ verts = g.vertices + (size_t)ib * g.V * 4;
     const float* __restrict__ cols = CK ? g.vertex_colors + (size_t)ib * g.V * CK : nullptr;
     auto fetch_colour = [&](int vid) {
@@ -96,80 +117,89 @@ __global__ __launch_bounds__(64) void setup_kernel_v2(GeomParams g)
         else if constexpr (CK == 3) { const Float3v q = *reinterpret_cast<const Float3v*>(cp); return make_float4(q.x, q.y, q.z, 0.f); }
         else return make_float4(cp[0], 0.f, 0.f, 0.f);
     };
-    // The face's indices and -- speculatively, for the identity triple (3f, 3f+1, 3f+2) of split-vertex meshes -- its vertices
-    // and colours are requested TOGETHER, branch-free (clamped addresses: a load inside a divergent branch is waited for
-    // inside it): one memory round trip instead of two for such meshes; any other mesh pays the unused requests and takes the
-    // second trip below.
-    int32_t idx[3];
-    float4 vv[3], cv[3];
-    {
-        const int32_t* __restrict__ fp = g.faces + (g.shared_faces ? (size_t)fs : n) * 3;
+    if (wave == 0) {
+        // The face's indices and -- speculatively, for the identity triple (3f, 3f+1, 3f+2) of split-vertex meshes -- its vertices
+        // and colours are requested TOGETHER, branch-free (clamped addresses: a load inside a divergent branch is waited for
+        // inside it): one memory round trip instead of two for such meshes; any other mesh pays the unused requests and takes the
+        // second trip below.
+        const int32_t* __restrict__ fp = g.faces + (g.shared_faces ? (size_t)fs : (size_t)ib * g.F + fs) * 3;
         idx[0] = fp[0]; idx[1] = fp[1]; idx[2] = fp[2];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int sv = min(3 * fs + k, g.V - 1);
-        vv[k] = *reinterpret_cast<const float4*>(verts + (size_t)sv * 4);
-        cv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (CK != 0) cv[k] = fetch_colour(sv);
-    }
-    for (int i = lane; i < nbins; i += 64) s_mask[i] = 0ull;
-    if (lane == 0) s_mask[big] = 0ull;
-    FMARK();  // 1 requests issued, masks cleared
-    const bool identity = 3 * fs + 2 < g.V && idx[0] == 3 * fs && idx[1] == 3 * fs + 1 && idx[2] == 3 * fs + 2;
-    if (__builtin_amdgcn_ballot_w64(have && !identity) != 0ull) {   // (wave-uniform) some face of the chunk is not the identity triple
-        int32_t ci[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ci[k] = identity ? 3 * fs + k : ((uint32_t)idx[k] < (uint32_t)g.V ? idx[k] : 0);   // a bad index reads vertex 0 (the face is dropped below)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            vv[k] = *reinterpret_cast<const float4*>(verts + (size_t)ci[k] * 4);
-            if constexpr (CK != 0) cv[k] = fetch_colour(ci[k]);
+            const int sv = min(3 * fs + k, g.V - 1);
+            vv[k] = *reinterpret_cast<const float4*>(verts + (size_t)sv * 4);
+            cv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (CK != 0) cv[k] = fetch_colour(sv);
         }
+    } else {
+        // the chunk's bin masks: cleared by the three waves that have nothing to wait for
+        for (int i = tid - 64; i < nbins; i += STHREADS - 64) s_mask[i] = 0ull;
+        if (tid == 64) s_mask[big] = 0ull;
     }
+    FMARK();  // 1 requests issued / masks cleared
     __syncthreads();
-    FMARK();  // 2 indices (+ vertices of the identity triple, or the second trip) there
-    if (have) {
-        FaceRec rec;
-        FaceBox box;
-        if (setup_face_from(vv, idx, g.V, g.H, g.W, rec, box)) {
-            if (g.v2_only) {   // raster_kernel_v2 reads the record's 96-byte head only (the depth plane is in the coverage record)
-                const uint4* src = reinterpret_cast<const uint4*>(&rec);
-                uint4* dst = reinterpret_cast<uint4*>(&g.recs[n]);
+    FMARK();  // 2 indices (+ vertices of the identity triple) there
+    if (wave == 0) {
+        const bool identity = 3 * fs + 2 < g.V && idx[0] == 3 * fs && idx[1] == 3 * fs + 1 && idx[2] == 3 * fs + 2;
+        if (__builtin_amdgcn_ballot_w64(have && !identity) != 0ull) {   // (wave-uniform) some face of the chunk is not the identity triple
+            int32_t ci[3];
 #pragma unroll
-                for (int i = 0; i < FACE_SHADE_BYTES / 16; ++i) dst[i] = src[i];
+            for (int k = 0; k < 3; ++k) ci[k] = identity ? 3 * fs + k : ((uint32_t)idx[k] < (uint32_t)g.V ? idx[k] : 0);   // a bad index reads vertex 0 (the face is dropped below)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                vv[k] = *reinterpret_cast<const float4*>(verts + (size_t)ci[k] * 4);
+                if constexpr (CK != 0) cv[k] = fetch_colour(ci[k]);
+            }
+        }
+        if (have) {
+            FaceRec rec;
+            FaceBox box;
+            if (setup_face_from(vv, idx, g.V, g.H, g.W, rec, box)) {
+                s_recs[lane] = rec;
+                TileRec lr;
+                make_local_rec(rec, f, box, g.H, (float)g.W, (float)g.H, &lr);
+                s_lrecs[lane] = lr;
+                if constexpr (CK != 0) { s_crecs[3 * lane] = cv[0]; s_crecs[3 * lane + 1] = cv[1]; s_crecs[3 * lane + 2] = cv[2]; }
+                const unsigned long long bit = 1ull << lane;
+                const int bx0 = box.i_min >> g.grid.shift, bx1 = box.i_max >> g.grid.shift;
+                const int by0 = box.r_min >> g.grid.shift, by1 = box.r_max >> g.grid.shift;
+                if ((bx1 - bx0 + 1) * (by1 - by0 + 1) <= MAX_FACE_BINS) {
+                    for (int by = by0; by <= by1; ++by)
+                        for (int bx = bx0; bx <= bx1; ++bx) atomicOr(&s_mask[by * g.grid.bins_x + bx], bit);
+                } else {
+                    atomicOr(&s_mask[big], bit);
+                }
+                if (!g.v2_only) {
+                    // (the {box, face} entry at its fixed slot: what dirt_raster.hip's kernels -- 16 x 16 tiles, other channel counts --
+                    // read behind the same masks)
+                    BinEntry e;
+                    e.box = box; e.face = f; e.pad = 0;
+                    g.entries[((size_t)ib * g.nchunk + chunk) * (5 * (size_t)g.chunk_faces) + lane] = e;
+                }
             } else {
-                g.recs[n] = rec;
+                s_recs[lane].flags = 0;   // (no bit anywhere: the rest of its records is never read)
             }
-            TileRec lr;
-            make_local_rec(rec, f, box, g.H, (float)g.W, (float)g.H, &lr);
-            g.lrecs[n] = lr;
-            if constexpr (CK != 0) { g.crecs[3 * n] = cv[0]; g.crecs[3 * n + 1] = cv[1]; g.crecs[3 * n + 2] = cv[2]; }
-            const unsigned long long bit = 1ull << lane;
-            const int bx0 = box.i_min >> g.grid.shift, bx1 = box.i_max >> g.grid.shift;
-            const int by0 = box.r_min >> g.grid.shift, by1 = box.r_max >> g.grid.shift;
-            if ((bx1 - bx0 + 1) * (by1 - by0 + 1) <= MAX_FACE_BINS) {
-                for (int by = by0; by <= by1; ++by)
-                    for (int bx = bx0; bx <= bx1; ++bx) atomicOr(&s_mask[by * g.grid.bins_x + bx], bit);
-            } else {
-                atomicOr(&s_mask[big], bit);
-            }
-            if (!g.v2_only) {
-                // (the {box, face} entry at its fixed slot: what dirt_raster.hip's kernels -- 16 x 16 tiles, other channel counts --
-                // read behind the same masks)
-                BinEntry e;
-                e.box = box; e.face = f; e.pad = 0;
-                g.entries[((size_t)ib * g.nchunk + chunk) * (5 * (size_t)g.chunk_faces) + lane] = e;
-            }
-        } else {
-            g.recs[n].flags = 0;   // (no bit anywhere: its records are never read)
         }
     }
-    FMARK();  // 3 set-up, record stores, masks
+    FMARK();  // 3 set-up, records in LDS, masks
     __syncthreads();
     FMARK();  // 4
-    // (two cells per lane and store: 16-byte accesses on both sides; the row starts at a 16-byte boundary)
-    for (int i = 2 * lane; i < nbins; i += 128) {
+    // ---- the chunk's records, contiguous in memory: linear copies of 16-byte pieces (8 + 5 + 3 per face) ----
+    {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(&s_recs[0]);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(g.recs + n0);
+        for (int i = tid; i < 8 * nf; i += STHREADS) dst[i] = src[i];
+        src = reinterpret_cast<const uint4*>(&s_lrecs[0]);
+        dst = reinterpret_cast<uint4*>(g.lrecs + n0);
+        for (int i = tid; i < 5 * nf; i += STHREADS) dst[i] = src[i];
+        if constexpr (CK != 0) {
+            src = reinterpret_cast<const uint4*>(&s_crecs[0]);
+            dst = reinterpret_cast<uint4*>(g.crecs + 3 * n0);
+            for (int i = tid; i < 3 * nf; i += STHREADS) dst[i] = src[i];
+        }
+    }
+    // ---- ... and its row of the directory (two cells per store: 16-byte accesses on both sides; rows start at 16-byte boundaries) ----
+    for (int i = 2 * tid; i < nbins; i += 2 * STHREADS) {
         if (i + 1 < nbins) {
             const ulonglong2 m = *reinterpret_cast<const ulonglong2*>(&s_mask[i]);
             *reinterpret_cast<ulonglong2*>(&row[i]) = m;
@@ -178,13 +208,13 @@ __global__ __launch_bounds__(64) void setup_kernel_v2(GeomParams g)
             row[i] = BinCell{(uint32_t)m, (uint32_t)(m >> 32)};
         }
     }
-    if (lane == 63) {
+    if (tid == STHREADS - 1) {
         const unsigned long long m = s_mask[big];
         row[big] = BinCell{(uint32_t)m, (uint32_t)(m >> 32)};
     }
-    FMARK();  // 5 directory stores issued
+    FMARK();  // 5 record and directory stores issued
 #ifdef DIRT_TRACE
-    if (lane == 0 && g_trace_fwd_setup) {
+    if (tid == 0 && g_trace_fwd_setup) {
         long long* o = g_trace_fwd_setup + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
         for (int i = 0; i < 12; ++i) o[i] = i < tr_n ? tr_t[i] : 0;
         o[12] = tr_wall0; o[13] = (long long)wall_clock64() - tr_wall0;
@@ -196,10 +226,10 @@ hipError_t launch_geometry_v2(const GeomParams& g, hipStream_t stream)
 {
     const dim3 grid((unsigned)g.nchunk, (unsigned)g.B);
     const int ck = g.crecs ? g.C : 0;
-    if (ck == 4) hipLaunchKernelGGL(setup_kernel_v2<4>, grid, dim3(64), 0, stream, g);
-    else if (ck == 3) hipLaunchKernelGGL(setup_kernel_v2<3>, grid, dim3(64), 0, stream, g);
-    else if (ck == 1) hipLaunchKernelGGL(setup_kernel_v2<1>, grid, dim3(64), 0, stream, g);
-    else hipLaunchKernelGGL(setup_kernel_v2<0>, grid, dim3(64), 0, stream, g);
+    if (ck == 4) hipLaunchKernelGGL(setup_kernel_v2<4>, grid, dim3(STHREADS), 0, stream, g.vertices, g.faces, g.vertex_colors, g.shared_faces, g.V, g.F, g);
+    else if (ck == 3) hipLaunchKernelGGL(setup_kernel_v2<3>, grid, dim3(STHREADS), 0, stream, g.vertices, g.faces, g.vertex_colors, g.shared_faces, g.V, g.F, g);
+    else if (ck == 1) hipLaunchKernelGGL(setup_kernel_v2<1>, grid, dim3(STHREADS), 0, stream, g.vertices, g.faces, g.vertex_colors, g.shared_faces, g.V, g.F, g);
+    else hipLaunchKernelGGL(setup_kernel_v2<0>, grid, dim3(STHREADS), 0, stream, g.vertices, g.faces, g.vertex_colors, g.shared_faces, g.V, g.F, g);
     return hipGetLastError();
 }
 
@@ -233,9 +263,17 @@ static_assert(sizeof(ShadeSlot<true>) == 144 && sizeof(ShadeSlot<false>) == 96, 
 #ifndef DIRT_V2_WAVES
 #define DIRT_V2_WAVES 4
 #endif
+// (The leading scalar arguments repeat the fields of `p_in` that the first memory trip is addressed with: gfx950 PRELOADS the
+// first kernel arguments into SGPRs while the wave is launched (-amdgpu-kernarg-preload-count, dirt_amd/build.py), so the
+// directory reads are issued without waiting for a first-touch scalar load of the kernel argument segment.)
 template <int MODE, int CSPEC, int WAVES = 4>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 8 : DIRT_V2_WAVES) void raster_kernel_v2(RasterParams p)
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 8 : DIRT_V2_WAVES) void raster_kernel_v2(
+    const BinCell* __restrict__ a_cells, int a_nchunk, int a_tiles_x, int a_tiles_y, uint32_t a_tiles_x_magic, int a_shift, int a_bins_x,
+    int a_big, int a_chunk_stride, RasterParams p_in)
 {
+    RasterParams p = p_in;
+    p.cells = a_cells; p.nchunk = a_nchunk; p.tiles_x = a_tiles_x; p.tiles_y = a_tiles_y; p.tiles_x_magic = a_tiles_x_magic;
+    p.grid.shift = a_shift; p.grid.bins_x = a_bins_x; p.grid.big = a_big; p.grid.cell_chunk_stride = a_chunk_stride;
     constexpr int NB = 2, NBY = WAVES == 8 ? 1 : 2, TILE = 32, PPL = NB * NBY, THREADS = 64 * WAVES, RH = 8 * NBY;
     constexpr bool COLOURS = MODE == 0;
     constexpr int SPARTS = COLOURS ? 9 : 6;
@@ -554,13 +592,15 @@ hipError_t launch_raster_v2(const RasterParams& p_in, int B, bool visibility_onl
 #else
     const bool w8 = (size_t)grid.x * grid.y <= 1024 && !visibility_only && !(p.flags & DIRT_FLAG_TILES_LARGE);
 #endif
-    if (visibility_only) hipLaunchKernelGGL((raster_kernel_v2<1, 4>), grid, dim3(RTHREADS), 0, stream, p);
-    else if (w8 && p.C == 4) hipLaunchKernelGGL((raster_kernel_v2<0, 4, 8>), grid, dim3(512), 0, stream, p);
-    else if (w8 && p.C == 3) hipLaunchKernelGGL((raster_kernel_v2<0, 3, 8>), grid, dim3(512), 0, stream, p);
-    else if (w8) hipLaunchKernelGGL((raster_kernel_v2<0, 1, 8>), grid, dim3(512), 0, stream, p);
-    else if (p.C == 4) hipLaunchKernelGGL((raster_kernel_v2<0, 4>), grid, dim3(RTHREADS), 0, stream, p);
-    else if (p.C == 3) hipLaunchKernelGGL((raster_kernel_v2<0, 3>), grid, dim3(RTHREADS), 0, stream, p);
-    else hipLaunchKernelGGL((raster_kernel_v2<0, 1>), grid, dim3(RTHREADS), 0, stream, p);
+#define V2_ARGS p.cells, p.nchunk, p.tiles_x, p.tiles_y, p.tiles_x_magic, p.grid.shift, p.grid.bins_x, p.grid.big, p.grid.cell_chunk_stride, p
+    if (visibility_only) hipLaunchKernelGGL((raster_kernel_v2<1, 4>), grid, dim3(RTHREADS), 0, stream, V2_ARGS);
+    else if (w8 && p.C == 4) hipLaunchKernelGGL((raster_kernel_v2<0, 4, 8>), grid, dim3(512), 0, stream, V2_ARGS);
+    else if (w8 && p.C == 3) hipLaunchKernelGGL((raster_kernel_v2<0, 3, 8>), grid, dim3(512), 0, stream, V2_ARGS);
+    else if (w8) hipLaunchKernelGGL((raster_kernel_v2<0, 1, 8>), grid, dim3(512), 0, stream, V2_ARGS);
+    else if (p.C == 4) hipLaunchKernelGGL((raster_kernel_v2<0, 4>), grid, dim3(RTHREADS), 0, stream, V2_ARGS);
+    else if (p.C == 3) hipLaunchKernelGGL((raster_kernel_v2<0, 3>), grid, dim3(RTHREADS), 0, stream, V2_ARGS);
+    else hipLaunchKernelGGL((raster_kernel_v2<0, 1>), grid, dim3(RTHREADS), 0, stream, V2_ARGS);
+#undef V2_ARGS
     return hipGetLastError();
 }
 
