@@ -77,7 +77,12 @@ __device__ inline bool setup_face(const float* __restrict__ verts, int V, const 
     return setup_face_from(vv, idx, V, H, W, rec, box);
 }
 
-__device__ inline bool setup_face_from(const float4 (&vv)[3], const int32_t (&idx)[3], int V, int H, int W, FaceRec& rec, FaceBox& box)
+// The set-up of one face in two independent halves (setup_face_from = both; setup_kernel_v2 runs them on different waves):
+//   setup_face_edges: index / finiteness checks, the edge functions' coefficients, det, the depth plane, the sign folding --
+//                     everything of the record but the box;
+//   setup_face_box  : the w > 0 count, the trivial depth rejection, the conservative pixel box.
+// A face is set up iff both return true.  Each is the corresponding part of the former single function, operation for operation.
+__device__ inline bool setup_face_edges(const float4 (&vv)[3], const int32_t (&idx)[3], int V, int H, int W, FaceRec& rec)
 {
     double X[3], Y[3], Wc[3], Z[3];
     const int32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
@@ -115,6 +120,41 @@ __device__ inline bool setup_face_from(const float4 (&vv)[3], const int32_t (&id
     const double inv_det = 1.0 / det;
     if (!isfinite(inv_det)) return false;
 
+    // depth plane from the unfolded coefficients (NDC depth = sum_k E_k * z_k / det is affine in the sample)
+    double zs[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) zs[k] = Z[k] * inv_det;
+    {
+        double m0, m1, m2;
+        m0 = a[0] * zs[0]; m1 = a[1] * zs[1]; m2 = a[2] * zs[2]; rec.zp[0] = ((m0 + m1) + m2) * 8388607.5;
+        m0 = b[0] * zs[0]; m1 = b[1] * zs[1]; m2 = b[2] * zs[2]; rec.zp[1] = ((m0 + m1) + m2) * 8388607.5;
+        m0 = c[0] * zs[0]; m1 = c[1] * zs[1]; m2 = c[2] * zs[2]; rec.zp[2] = fma((m0 + m1) + m2, 8388607.5, 8388607.5);
+    }
+    uint32_t flags = FACE_VALID;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool incl = (a[k] > 0.0) || (a[k] == 0.0 && b[k] > 0.0);
+        if (!incl) { a[k] = -a[k]; b[k] = -b[k]; c[k] = -c[k]; flags |= (1u << k); }
+        rec.coef[3 * k + 0] = a[k]; rec.coef[3 * k + 1] = b[k]; rec.coef[3 * k + 2] = c[k];
+    }
+    rec.flags = flags; rec.pad0 = 0; rec.pad1 = 0;
+    rec.inv_det = inv_det;
+    return true;
+}
+
+// (Vertices that setup_face_edges rejects -- bad indices, non-finite components -- may reach this half: it then returns
+// anything, without trapping; the face is dropped by the other half.)
+__device__ inline bool setup_face_box(const float4 (&vv)[3], int H, int W, FaceBox& box)
+{
+    double X[3], Y[3], Wc[3], Z[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 v = vv[k];
+        X[k] = ((double)v.x + (double)v.w) * (0.5 * (double)W);
+        Y[k] = ((double)v.y + (double)v.w) * (0.5 * (double)H);
+        Wc[k] = (double)v.w;
+        Z[k] = (double)v.z;
+    }
     const int npos = (Wc[0] > 0.0) + (Wc[1] > 0.0) + (Wc[2] > 0.0);
     if (npos == 0) return false;
     int i_min = 0, i_max = W - 1, j_min = 0, j_max = H - 1;
@@ -146,29 +186,15 @@ __device__ inline bool setup_face_from(const float4 (&vv)[3], const int32_t (&id
         if (hi < (float)j_max) j_max = (int)hi;
     }
     if (i_min > i_max || j_min > j_max) return false;
-
-    // depth plane from the unfolded coefficients (NDC depth = sum_k E_k * z_k / det is affine in the sample)
-    double zs[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) zs[k] = Z[k] * inv_det;
-    {
-        double m0, m1, m2;
-        m0 = a[0] * zs[0]; m1 = a[1] * zs[1]; m2 = a[2] * zs[2]; rec.zp[0] = ((m0 + m1) + m2) * 8388607.5;
-        m0 = b[0] * zs[0]; m1 = b[1] * zs[1]; m2 = b[2] * zs[2]; rec.zp[1] = ((m0 + m1) + m2) * 8388607.5;
-        m0 = c[0] * zs[0]; m1 = c[1] * zs[1]; m2 = c[2] * zs[2]; rec.zp[2] = fma((m0 + m1) + m2, 8388607.5, 8388607.5);
-    }
-    uint32_t flags = FACE_VALID;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const bool incl = (a[k] > 0.0) || (a[k] == 0.0 && b[k] > 0.0);
-        if (!incl) { a[k] = -a[k]; b[k] = -b[k]; c[k] = -c[k]; flags |= (1u << k); }
-        rec.coef[3 * k + 0] = a[k]; rec.coef[3 * k + 1] = b[k]; rec.coef[3 * k + 2] = c[k];
-    }
-    rec.flags = flags; rec.pad0 = 0; rec.pad1 = 0;
-    rec.inv_det = inv_det;
     box.i_min = (int16_t)i_min; box.i_max = (int16_t)i_max;
     box.r_min = (int16_t)(H - 1 - j_max); box.r_max = (int16_t)(H - 1 - j_min);
     return true;
+}
+
+__device__ inline bool setup_face_from(const float4 (&vv)[3], const int32_t (&idx)[3], int V, int H, int W, FaceRec& rec, FaceBox& box)
+{
+    if (!setup_face_edges(vv, idx, V, H, W, rec)) return false;
+    return setup_face_box(vv, H, W, box);
 }
 
 // Folded edge functions of one record at a sample.

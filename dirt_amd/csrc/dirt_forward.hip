@@ -71,12 +71,19 @@ __device__ __forceinline__ uint32_t lds_address(T* p)
 
 // ---- set-up ----------------------------------------------------------------------------------------------------------
 // CK: the channel count whose vertex colours ride along (1, 3, 4), or 0: none (the visibility / stateless backward passes).
-// One workgroup of FOUR waves per chunk of 64 faces.  The chip is almost empty while this kernel runs (157 chunks at K3) and a
-// wave's time is its instruction count (profiles/EXPERIMENTS.md): wave 0 keeps the dependent chain -- requests, the face's
-// arithmetic (one face per lane), its bits in the bin masks -- and leaves its three records in LDS; the other three waves
-// clear the masks meanwhile, and afterwards all four copy the records out as whole 16-byte runs (a lane storing its own
-// 128 + 80 + 48 bytes touches 64 lines per store instruction; the chunk's records are CONTIGUOUS in memory, so the copy is
-// linear) and store the chunk's row of the directory.  (Rounds 5-6a: one wave did everything: 8 195 clocks.)
+// One workgroup of FOUR waves per chunk of 64 faces, one face per lane in EVERY wave, each wave with its own part of the face's
+// set-up.  The chip is almost empty while this kernel runs (157 chunks at K3) and a wave's time is its instruction count
+// (profiles/EXPERIMENTS.md), so the ~700-instruction chain of a face is cut across waves instead of lanes:
+//   wave 0  the edge functions, det, depth plane, sign folding -> the set-up record (setup_face_edges), left in LDS;
+//   wave 1  the conservative pixel box (setup_face_box); after the barrier, once wave 0's verdict is known: the face's bit in
+//           the mask of every bin the box touches;
+//   wave 2  clears the chunk's 1 026 masks while the others wait for their vertices; after the barrier: the face-local float32
+//           coverage record from wave 0's record and wave 1's box (make_local_rec);
+//   wave 3  fetches the three vertex colours (its own request of the indices) -> the colour record.
+// Waves 0, 1, 3 each request the indices and -- speculatively, for the identity triple -- their vertices / colours themselves
+// (a few hundred bytes more through the L2 instead of a dependent LDS hand-over).  All records go through LDS and leave as
+// linear 16-byte runs: the chunk's records are contiguous in memory (8 + 5 + 3 KB).
+// (Rounds 5-6a: one wave did everything, 8 195 clocks; four waves with the arithmetic still on one: 7 621.)
 constexpr int STHREADS = 256;
 // (Leading scalar arguments = the fields the first trip is addressed with, PRELOADED into SGPRs at wave launch: see raster_kernel_v2.)
 template <int CK>
@@ -90,8 +97,10 @@ __global__ __launch_bounds__(STHREADS) void setup_kernel_v2(const float* __restr
     __shared__ __align__(16) FaceRec s_recs[64];
     __shared__ __align__(16) TileRec s_lrecs[64];
     __shared__ __align__(16) float4 s_crecs[CK ? 3 * 64 : 1];
+    __shared__ FaceBox s_box[64];
+    __shared__ uint8_t s_ok_edges[64], s_ok_box[64];
     const int ib = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0 edges, 1 box + masks, 2 mask clearing + local records, 3 colours
     FTRACE_DECL();
     FMARK();  // 0 start
     const int nbins = g.grid.bins_x * g.grid.bins_y, big = g.grid.big;
@@ -103,102 +112,114 @@ __global__ __launch_bounds__(STHREADS) void setup_kernel_v2(const float* __restr
     const int f0 = chunk * 64;
     const int nf = min(64, g.F - f0);            // faces of this chunk (the last one may be short)
     const size_t n0 = (size_t)ib * g.F + f0;     // ... and their first record
-    // wave 0's registers across the first barrier
-    int32_t idx[3] = {0, 0, 0};
-    float4 vv[3], cv[3];
     const int f = f0 + lane;
-    const bool have = wave == 0 && lane < nf;
-    const int fs = lane < nf ? f : 0;            // (lanes past the last face: face 0, nothing stored)
+    const bool have = lane < nf;
+    const int fs = have ? f : 0;                 // (lanes past the last face: face 0, nothing stored)
     const float* __restrict__ verts = g.vertices + (size_t)ib * g.V * 4;
     const float* __restrict__ cols = CK ? g.vertex_colors + (size_t)ib * g.V * CK : nullptr;
-    auto fetch_colour = [&](int vid) {
-        const float* __restrict__ cp = cols + (size_t)vid * CK;
-        if constexpr (CK == 4) return *reinterpret_cast<const float4*>(cp);
-        else if constexpr (CK == 3) { const Float3v q = *reinterpret_cast<const Float3v*>(cp); return make_float4(q.x, q.y, q.z, 0.f); }
-        else return make_float4(cp[0], 0.f, 0.f, 0.f);
+    // what a role reads of a vertex: its clip-space position, or (role 3) its colour
+    auto fetch = [&](int vid) {
+        if (role != 3) return *reinterpret_cast<const float4*>(verts + (size_t)vid * 4);
+        if constexpr (CK == 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+        else {
+            const float* __restrict__ cp = cols + (size_t)vid * CK;
+            if constexpr (CK == 4) return *reinterpret_cast<const float4*>(cp);
+            else if constexpr (CK == 3) { const Float3v q = *reinterpret_cast<const Float3v*>(cp); return make_float4(q.x, q.y, q.z, 0.f); }
+            else return make_float4(cp[0], 0.f, 0.f, 0.f);
+        }
     };
-    if (wave == 0) {
+    int32_t idx[3] = {0, 0, 0};
+    float4 vv[3];
+    const bool fetches = role != 2 && (role != 3 || CK != 0);
+    if (fetches) {
         // The face's indices and -- speculatively, for the identity triple (3f, 3f+1, 3f+2) of split-vertex meshes -- its vertices
-        // and colours are requested TOGETHER, branch-free (clamped addresses: a load inside a divergent branch is waited for
-        // inside it): one memory round trip instead of two for such meshes; any other mesh pays the unused requests and takes the
-        // second trip below.
+        // (colours) are requested TOGETHER, branch-free (clamped addresses: a load inside a divergent branch is waited for inside
+        // it): one memory round trip instead of two for such meshes; any other mesh pays the unused requests and takes the second
+        // trip below.
         const int32_t* __restrict__ fp = g.faces + (g.shared_faces ? (size_t)fs : (size_t)ib * g.F + fs) * 3;
         idx[0] = fp[0]; idx[1] = fp[1]; idx[2] = fp[2];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int sv = min(3 * fs + k, g.V - 1);
-            vv[k] = *reinterpret_cast<const float4*>(verts + (size_t)sv * 4);
-            cv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (CK != 0) cv[k] = fetch_colour(sv);
-        }
-    } else {
-        // the chunk's bin masks: cleared by the three waves that have nothing to wait for
-        for (int i = tid - 64; i < nbins; i += STHREADS - 64) s_mask[i] = 0ull;
-        if (tid == 64) s_mask[big] = 0ull;
+        for (int k = 0; k < 3; ++k) vv[k] = fetch(min(3 * fs + k, g.V - 1));
+    } else if (role == 2) {
+        for (int i = lane; i < nbins; i += 64) s_mask[i] = 0ull;
+        if (lane == 0) s_mask[big] = 0ull;
     }
     FMARK();  // 1 requests issued / masks cleared
-    __syncthreads();
-    FMARK();  // 2 indices (+ vertices of the identity triple) there
-    if (wave == 0) {
+    if (fetches) {
         const bool identity = 3 * fs + 2 < g.V && idx[0] == 3 * fs && idx[1] == 3 * fs + 1 && idx[2] == 3 * fs + 2;
         if (__builtin_amdgcn_ballot_w64(have && !identity) != 0ull) {   // (wave-uniform) some face of the chunk is not the identity triple
-            int32_t ci[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) ci[k] = identity ? 3 * fs + k : ((uint32_t)idx[k] < (uint32_t)g.V ? idx[k] : 0);   // a bad index reads vertex 0 (the face is dropped below)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                vv[k] = *reinterpret_cast<const float4*>(verts + (size_t)ci[k] * 4);
-                if constexpr (CK != 0) cv[k] = fetch_colour(ci[k]);
-            }
-        }
-        if (have) {
-            FaceRec rec;
-            FaceBox box;
-            if (setup_face_from(vv, idx, g.V, g.H, g.W, rec, box)) {
-                s_recs[lane] = rec;
-                TileRec lr;
-                make_local_rec(rec, f, box, g.H, (float)g.W, (float)g.H, &lr);
-                s_lrecs[lane] = lr;
-                if constexpr (CK != 0) { s_crecs[3 * lane] = cv[0]; s_crecs[3 * lane + 1] = cv[1]; s_crecs[3 * lane + 2] = cv[2]; }
-                const unsigned long long bit = 1ull << lane;
-                const int bx0 = box.i_min >> g.grid.shift, bx1 = box.i_max >> g.grid.shift;
-                const int by0 = box.r_min >> g.grid.shift, by1 = box.r_max >> g.grid.shift;
-                if ((bx1 - bx0 + 1) * (by1 - by0 + 1) <= MAX_FACE_BINS) {
-                    for (int by = by0; by <= by1; ++by)
-                        for (int bx = bx0; bx <= bx1; ++bx) atomicOr(&s_mask[by * g.grid.bins_x + bx], bit);
-                } else {
-                    atomicOr(&s_mask[big], bit);
-                }
-                if (!g.v2_only) {
-                    // (the {box, face} entry at its fixed slot: what dirt_raster.hip's kernels -- 16 x 16 tiles, other channel counts --
-                    // read behind the same masks)
-                    BinEntry e;
-                    e.box = box; e.face = f; e.pad = 0;
-                    g.entries[((size_t)ib * g.nchunk + chunk) * (5 * (size_t)g.chunk_faces) + lane] = e;
-                }
-            } else {
-                s_recs[lane].flags = 0;   // (no bit anywhere: the rest of its records is never read)
+                const int ci = identity ? 3 * fs + k : ((uint32_t)idx[k] < (uint32_t)g.V ? idx[k] : 0);   // a bad index reads vertex 0 (the face is dropped by setup_face_edges)
+                vv[k] = fetch(ci);
             }
         }
     }
-    FMARK();  // 3 set-up, records in LDS, masks
+    FMARK();  // 2 indices and vertices there
+    bool ok_mine = false;
+    FaceBox box;
+    box.i_min = 0; box.i_max = -1; box.r_min = 0; box.r_max = -1;
+    if (role == 0) {
+        FaceRec rec;
+        ok_mine = have && setup_face_edges(vv, idx, g.V, g.H, g.W, rec);
+        if (ok_mine) s_recs[lane] = rec;
+        else s_recs[lane].flags = 0;   // (no bit anywhere: the rest of its records is never read)
+        s_ok_edges[lane] = ok_mine ? 1 : 0;
+    } else if (role == 1) {
+        ok_mine = have && setup_face_box(vv, g.H, g.W, box);
+        s_box[lane] = box;
+        s_ok_box[lane] = ok_mine ? 1 : 0;
+    } else if (role == 3) {
+        if constexpr (CK != 0) { s_crecs[3 * lane] = vv[0]; s_crecs[3 * lane + 1] = vv[1]; s_crecs[3 * lane + 2] = vv[2]; }
+    }
+    FMARK();  // 3 this wave's part of the set-up, in LDS
     __syncthreads();
-    FMARK();  // 4
-    // ---- the chunk's records, contiguous in memory: linear copies of 16-byte pieces (8 + 5 + 3 per face) ----
-    {
+    if (role == 1) {
+        if (ok_mine && s_ok_edges[lane]) {
+            const unsigned long long bit = 1ull << lane;
+            const int bx0 = box.i_min >> g.grid.shift, bx1 = box.i_max >> g.grid.shift;
+            const int by0 = box.r_min >> g.grid.shift, by1 = box.r_max >> g.grid.shift;
+            if ((bx1 - bx0 + 1) * (by1 - by0 + 1) <= MAX_FACE_BINS) {
+                for (int by = by0; by <= by1; ++by)
+                    for (int bx = bx0; bx <= bx1; ++bx) atomicOr(&s_mask[by * g.grid.bins_x + bx], bit);
+            } else {
+                atomicOr(&s_mask[big], bit);
+            }
+            if (!g.v2_only) {
+                // (the {box, face} entry at its fixed slot: what dirt_raster.hip's kernels -- 16 x 16 tiles, other channel counts --
+                // read behind the same masks)
+                BinEntry e;
+                e.box = box; e.face = f; e.pad = 0;
+                g.entries[((size_t)ib * g.nchunk + chunk) * (5 * (size_t)g.chunk_faces) + lane] = e;
+            }
+        }
+    } else if (role == 2) {
+        if (have && s_ok_edges[lane] && s_ok_box[lane]) {
+            TileRec lr;
+            make_local_rec(s_recs[lane], f, s_box[lane], g.H, (float)g.W, (float)g.H, &lr);
+            s_lrecs[lane] = lr;
+        }
+    } else if (role == 0) {
+        // (meanwhile: the set-up records leave, 8 pieces of 16 bytes per face, linear)
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(&s_recs[0]);
         uint4* __restrict__ dst = reinterpret_cast<uint4*>(g.recs + n0);
-        for (int i = tid; i < 8 * nf; i += STHREADS) dst[i] = src[i];
-        src = reinterpret_cast<const uint4*>(&s_lrecs[0]);
-        dst = reinterpret_cast<uint4*>(g.lrecs + n0);
-        for (int i = tid; i < 5 * nf; i += STHREADS) dst[i] = src[i];
+        for (int i = lane; i < 8 * nf; i += 64) dst[i] = src[i];
+    } else {
         if constexpr (CK != 0) {
-            src = reinterpret_cast<const uint4*>(&s_crecs[0]);
-            dst = reinterpret_cast<uint4*>(g.crecs + 3 * n0);
-            for (int i = tid; i < 3 * nf; i += STHREADS) dst[i] = src[i];
+            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(&s_crecs[0]);
+            uint4* __restrict__ dst = reinterpret_cast<uint4*>(g.crecs + 3 * n0);
+            for (int i = lane; i < 3 * nf; i += 64) dst[i] = src[i];
         }
     }
-    // ---- ... and its row of the directory (two cells per store: 16-byte accesses on both sides; rows start at 16-byte boundaries) ----
+    __syncthreads();
+    FMARK();  // 4 masks and local records complete
+    // ---- the chunk's coverage records (5 pieces per face, linear) and its row of the directory (two cells per store: 16-byte
+    //      accesses on both sides; rows start at 16-byte boundaries) ----
+    {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(&s_lrecs[0]);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(g.lrecs + n0);
+        for (int i = tid; i < 5 * nf; i += STHREADS) dst[i] = src[i];
+    }
     for (int i = 2 * tid; i < nbins; i += 2 * STHREADS) {
         if (i + 1 < nbins) {
             const ulonglong2 m = *reinterpret_cast<const ulonglong2*>(&s_mask[i]);

@@ -42,7 +42,8 @@ def report(buf, nt, names, title):
     return a
 
 
-report(bs, 6, ['requests + clear masks', 'wait for indices / vertices (+ second trip)', 'set-up, records, masks', 'barrier', 'directory stores'], 'setup_kernel_v2')
+report(bs, 6, ['requests issued', 'indices / vertices there (+ second trip)', 'edge functions -> set-up record in LDS', 'barrier, records out, barrier',
+               'coverage records + directory stores'], 'setup_kernel_v2 (wave 0 of each chunk)')
 a = report(br, 10, ['cells requested, side job', 'barrier', 'wait cells, claim slots, list', 'barrier', 'coverage records: DMA + wait', 'barrier',
                     'shade DMA issue + coverage loop', 'wait shade data + barrier', 'shade + stores'], 'raster_kernel_v2')
 print('  candidates visited per wave: mean %.1f max %d' % (a[:, 15].mean(), a[:, 15].max()))
