@@ -606,12 +606,14 @@ hipError_t launch_raster_v2(const RasterParams& p_in, int B, bool visibility_onl
         p.zero_b_per = (unsigned)((p.zero_b_bytes / 16 + nwg - 1) / nwg);
         p.zero_c_per = (unsigned)((p.zero_c_bytes / 16 + nwg - 1) / nwg);
     }
-    // half-size waves (eight per workgroup) where every workgroup of the launch is resident at once -- at most four 512-thread
+    // half-size waves (eight per workgroup) where (nearly) every workgroup of the launch is resident at once -- four 512-thread
     // workgroups per compute unit --: such a launch ends with its heaviest wave (profiles/EXPERIMENTS.md round 6)
 #ifdef DIRT_V2_NO_W8
     const bool w8 = false;
+#elif defined(DIRT_V2_W8_ALWAYS)   // (A/B build)
+    const bool w8 = !visibility_only;
 #else
-    const bool w8 = (size_t)grid.x * grid.y <= 1024 && !visibility_only && !(p.flags & DIRT_FLAG_TILES_LARGE);
+    const bool w8 = (size_t)grid.x * grid.y <= 2048 && !visibility_only && !(p.flags & DIRT_FLAG_TILES_LARGE);   // (measured: 1024 tiles -2 us, 2048 -1.5, 4096 and more +5...10)
 #endif
 #define V2_ARGS p.cells, p.nchunk, p.tiles_x, p.tiles_y, p.tiles_x_magic, p.grid.shift, p.grid.bins_x, p.grid.big, p.grid.cell_chunk_stride, p
     if (visibility_only) hipLaunchKernelGGL((raster_kernel_v2<1, 4>), grid, dim3(RTHREADS), 0, stream, V2_ARGS);
