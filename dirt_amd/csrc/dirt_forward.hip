@@ -282,7 +282,7 @@ static_assert(sizeof(ShadeSlot<true>) == 144 && sizeof(ShadeSlot<false>) == 96, 
 // 16 x 8 region = 2 x 1 blocks -- for launches whose workgroups are all resident at once (one scene of 1024 x 1024): the
 // kernel then ends with its heaviest wave, and half-size waves halve that wave's serial candidate loop and its shading.
 #ifndef DIRT_V2_WAVES
-#define DIRT_V2_WAVES 4
+#define DIRT_V2_WAVES 6   // waves per SIMD the four-wave shape is compiled for: 80 VGPRs, six 22 KB workgroups per CU (round 6: 4 -> 6: raster -2.4...-5 % in multi-round launches)
 #endif
 // (The leading scalar arguments repeat the fields of `p_in` that the first memory trip is addressed with: gfx950 PRELOADS the
 // first kernel arguments into SGPRs while the wave is launched (-amdgpu-kernarg-preload-count, dirt_amd/build.py), so the
@@ -492,8 +492,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 8 : DIRT_V2_WAVES) void ra
     // candidates instead was measured: K3 raster 20.7 against 18.3 us -- 16 MB of requests in front of the directory reads.)
     constexpr bool BG_FIRST = WAVES != 8;
     const float* __restrict__ cols = COLOURS ? p.vertex_colors + (size_t)ib * p.V * C : nullptr;
+    // (opaque copies of the lane's first pixel: the other pixels' coordinates are re-derived here, one add each, instead of
+    // being kept -- at a register bound: spilled -- from the prologue through the coverage loop)
+    int xs0 = x0, rs0 = r0;
+    asm volatile("" : "+v"(xs0), "+v"(rs0));
     auto pixel_index = [&](int k, bool& inside) {
-        const int x = x0 + 8 * (k % NB), r = r0 + 8 * (k / NB);
+        const int x = xs0 + 8 * (k % NB), r = rs0 + 8 * (k / NB);
         inside = x < p.W && r < p.H;
         return ((size_t)ib * p.H + min(r, p.H - 1)) * p.W + min(x, p.W - 1);
     };
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 8 : DIRT_V2_WAVES) void ra
             flags = rec->flags; inv_det = rec->inv_det;
         }
         double Fk[3];
-        edge_eval(cf, (double)(x0 + 8 * (k % NB)) + 0.5, (double)(p.H - 1 - (r0 + 8 * (k / NB))) + 0.5, Fk);
+        edge_eval(cf, (double)(xs0 + 8 * (k % NB)) + 0.5, (double)(p.H - 1 - (rs0 + 8 * (k / NB))) + 0.5, Fk);
         float b[3], cw;
         bary_eval(Fk, flags, inv_det, b, cw);
         const float b0 = b[0], b1 = b[1], b2 = b[2];
