@@ -256,7 +256,7 @@ dirt::GeomParams geom_params(const Carved& c, const float* vertices, const int32
     dirt::chunking(F, g.nchunk, g.chunk_faces);
     g.masked = dirt::directory_is_masked(g.chunk_faces) ? 1 : 0;
     g.B = B; g.V = V; g.F = F; g.H = H; g.W = W;
-    g.grid = dirt::make_bin_grid(H, W, g.nchunk, g.masked != 0);
+    g.grid = dirt::make_bin_grid(H, W, g.nchunk, g.masked != 0, dirt::raster_tile_choice(H, W, B, flags) == 16 ? 4 : 5);
     g.v2_only = 0;
     g.lrecs = g.masked ? c.lrecs : nullptr;
     // the faces' vertex colours ride along for the forward pass of 1 / 3 / 4-channel images (raster_kernel_v2)

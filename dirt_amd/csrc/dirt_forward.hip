@@ -584,16 +584,26 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 8 : DIRT_V2_WAVES) void ra
 #endif
 }
 
+// The forward / visibility kernels' tile: 32 x 32 pixels unless that leaves the chip mostly idle (fewer than two workgroups
+// per CU), then 16 x 16 -- or pinned.  The bin grid is sized for this very choice (dirt_capi.hip::geom_params: 16-pixel bins
+// under 16 x 16 tiles, so that a bin's faces are a tile's candidates there too: K3-256 step -0.5 us).
+int raster_tile_choice(int H, int W, int B, unsigned flags)
+{
+    const long long tiles32 = (long long)((W + 31) / 32) * ((H + 31) / 32) * B;
+    int tile = tiles32 >= 512 ? 32 : 16;
+    if (flags & DIRT_FLAG_TILES_LARGE) tile = 32;
+    if (flags & DIRT_FLAG_TILES_SMALL) tile = 16;
+    return tile;
+}
+
 // Which launches take the two-trip kernel: the masked directory with its face-local records (meshes of up to 16 384 faces),
-// 32 x 32-pixel tiles (the library's choice from 512 such tiles on, or pinned), 1 / 3 / 4 channels or the visibility pass.
+// 32 x 32-pixel tiles, 1 / 3 / 4 channels or the visibility pass.  (A 16 x 16-tile shape of it -- a wave per 8 x 8 block --
+// was built and measured at K3-256: 29.2-29.3 us against 28.7-29.2 for dirt_raster.hip's 16 x 16 kernel on the same
+// 16-pixel bins, whose two-candidates-per-trip loop it lacks: not kept; profiles/EXPERIMENTS.md round 6.)
 bool raster_v2_applies(const RasterParams& p, int B, bool visibility_only)
 {
     if (!p.masked || p.lrecs == nullptr) return false;
-    const long long tiles32 = (long long)((p.W + 31) / 32) * ((p.H + 31) / 32) * B;
-    int tile = tiles32 >= 512 ? 32 : 16;
-    if (p.flags & DIRT_FLAG_TILES_LARGE) tile = 32;
-    if (p.flags & DIRT_FLAG_TILES_SMALL) tile = 16;
-    if (tile != 32) return false;
+    if (raster_tile_choice(p.H, p.W, B, p.flags) != 32) return false;
     if (visibility_only) return true;
     return (p.C == 1 || p.C == 3 || p.C == 4) && p.crecs != nullptr;
 }

@@ -108,7 +108,8 @@ struct GradParams {
     float inv_w, inv_h;        // 1 / W, 1 / H (pixel -> NDC: ndc_of), filled by launch_grad
 };
 
-BinGrid make_bin_grid(int H, int W, int nchunk, bool masked);
+BinGrid make_bin_grid(int H, int W, int nchunk, bool masked, int min_shift = 5);
+int raster_tile_choice(int H, int W, int B, unsigned flags);   // 32 or 16: the forward / visibility kernels' tile (dirt_forward.hip)
 void chunking(int F, int& nchunk, int& chunk_faces);
 #ifdef DIRT_NO_MASKED_DIR   // (A/B builds: rounds 1-4's start / count directory for every mesh)
 inline bool directory_is_masked(int) { return false; }

@@ -697,14 +697,14 @@ void chunking(int F, int& nchunk, int& chunk_faces)
     nchunk = F > 0 ? (F + chunk_faces - 1) / chunk_faces : 1;
 }
 
-BinGrid make_bin_grid(int H, int W, int nchunk, bool masked)
+BinGrid make_bin_grid(int H, int W, int nchunk, bool masked, int min_shift)
 {
     BinGrid g;
     const int max_bins = masked ? MAX_BINS_MASKED : MAX_BINS;
     g.big = max_bins;
     g.cell_bin_stride = masked ? 1 : nchunk;
     g.cell_chunk_stride = masked ? ((max_bins + 2) & ~1) : 1;   // (even: a chunk's row starts at a 16-byte boundary)
-    g.shift = 5;  // bins of >= 32 pixels: a raster tile (32 or 16 pixels) never straddles two bins
+    g.shift = masked ? min_shift : 5;  // bins of >= 32 pixels (16 for launches on 16 x 16 tiles: a bin's faces are then a tile's candidates there too): a raster tile never straddles two bins
     while (((W + (1 << g.shift) - 1) >> g.shift) * ((H + (1 << g.shift) - 1) >> g.shift) > max_bins) ++g.shift;
     g.bins_x = (W + (1 << g.shift) - 1) >> g.shift;
     g.bins_y = (H + (1 << g.shift) - 1) >> g.shift;
@@ -716,11 +716,7 @@ hipError_t launch_raster(const RasterParams& p_in, int B, bool visibility_only, 
     if (B == 0) return hipSuccess;
     if (raster_v2_applies(p_in, B, visibility_only)) return launch_raster_v2(p_in, B, visibility_only, stream);
     RasterParams p = p_in;
-    // 32 x 32 tiles unless that leaves the chip mostly idle (fewer than two workgroups per CU): then 16 x 16
-    const long long tiles32 = (long long)((p.W + 31) / 32) * ((p.H + 31) / 32) * B;
-    int tile = tiles32 >= 512 ? 32 : 16;
-    if (p.flags & DIRT_FLAG_TILES_LARGE) tile = 32;
-    if (p.flags & DIRT_FLAG_TILES_SMALL) tile = 16;
+    const int tile = raster_tile_choice(p.H, p.W, B, p.flags);   // (the bin grid was sized for this very choice: dirt_capi.hip::geom_params)
     p.tiles_x = (p.W + tile - 1) / tile;
     p.tiles_y = (p.H + tile - 1) / tile;
     p.tiles_x_magic = tile_magic(p.tiles_x);
