@@ -9,7 +9,8 @@
 // Rounds 1-5: a raster tile walked directory -> entries {box, face} -> set-up records -> vertex colours: FOUR dependent memory
 // round trips and three workgroup barriers before the first sample was tested -- 7.3 of the kernel's 18.7 us at K3, the same
 // whether 576 or 1024 tiles are rendered (profiles/EXPERIMENTS.md, round 4 knock-outs).  Here:
-//   * setup_kernel_v2 (one wave per chunk of 64 faces, one face per lane) writes per face, besides the 128-byte set-up
+//   * setup_kernel_v2 (a workgroup of four waves per chunk of 64 faces, one face per lane in each, every wave its own part of
+//     the face's set-up) writes per face, besides the 128-byte set-up
 //     record, its FACE-LOCAL coverage record (make_local_rec: float32 edge functions about the top-left pixel of the face's own
 //     box + certified bound + f64 depth plane + box: the 80 bytes the coverage loop reads, valid for every tile) and its three
 //     vertex colours as float4s; bins are 32-pixel squares -- the raster tiles themselves up to 1024 x 1024 -- so a bin's
@@ -20,6 +21,8 @@
 //     is ONE round of LDS-DMA: the candidates' 80-byte coverage records straight into LDS (lane <-> 16-byte piece, linear),
 //     then -- issued behind them, landing while the coverage loop runs -- the 96-byte heads of their set-up records and their
 //     colours for the shading pass.  Coverage, depth and shading arithmetic are dirt_raster.hip's (dirt_raster_common.h).
+//     Two shapes: four waves per 32 x 32 tile (16 x 16 pixels each), and eight half-size waves for launches of at most 2048
+//     tiles, which end with their heaviest wave.
 #include "dirt_device.h"
 #include "dirt_launch.h"
 #include "dirt_raster_common.h"
