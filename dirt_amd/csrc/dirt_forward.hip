@@ -594,8 +594,8 @@ int raster_tile_choice(int H, int W, int B, unsigned flags)
 {
     const long long tiles32 = (long long)((W + 31) / 32) * ((H + 31) / 32) * B;
     int tile = tiles32 >= 512 ? 32 : 16;
-    if (flags & DIRT_FLAG_TILES_LARGE) tile = 32;
     if (flags & DIRT_FLAG_TILES_SMALL) tile = 16;
+    if (flags & DIRT_FLAG_TILES_LARGE) tile = 32;   // (both bits: 32 x 32 tiles, eight waves each: launch_raster_v2)
     return tile;
 }
 
@@ -630,7 +630,8 @@ hipError_t launch_raster_v2(const RasterParams& p_in, int B, bool visibility_onl
 #elif defined(DIRT_V2_W8_ALWAYS)   // (A/B build)
     const bool w8 = !visibility_only;
 #else
-    const bool w8 = (size_t)grid.x * grid.y <= 2048 && !visibility_only && !(p.flags & DIRT_FLAG_TILES_LARGE);   // (measured: 1024 tiles -2 us, 2048 -1.5, 4096 and more +5...10)
+    const bool pinned8 = (p.flags & (DIRT_FLAG_TILES_LARGE | DIRT_FLAG_TILES_SMALL)) == (DIRT_FLAG_TILES_LARGE | DIRT_FLAG_TILES_SMALL);
+    const bool w8 = !visibility_only && (pinned8 || ((size_t)grid.x * grid.y <= 2048 && !(p.flags & DIRT_FLAG_TILES_LARGE)));   // (measured: 1024 tiles -2 us, 2048 -1.5, 4096 and more +5...10)
 #endif
 #define V2_ARGS p.cells, p.nchunk, p.tiles_x, p.tiles_y, p.tiles_x_magic, p.grid.shift, p.grid.bins_x, p.grid.big, p.grid.cell_chunk_stride, p
     if (visibility_only) hipLaunchKernelGGL((raster_kernel_v2<1, 4>), grid, dim3(RTHREADS), 0, stream, V2_ARGS);

@@ -89,7 +89,11 @@ extern "C" {
 #define DIRT_FLAG_TILES_LARGE 0x200u /* pin the forward / visibility kernels' tile shape instead of letting the library
                                        choose it from the frame size and the face density: 32x32 pixel tiles ... */
 #define DIRT_FLAG_TILES_SMALL 0x400u /* ... or 16x16.  Results do not depend on the shape (pixels and visibility bit for
-                                       bit); for tests.  (The gradient kernel's shapes: DIRT_FLAG_GRAD_*.) */
+                                       bit); for tests.  (The gradient kernel's shapes: DIRT_FLAG_GRAD_*.)  BOTH bits:
+                                       32x32 tiles rendered by EIGHT half-size waves each, the shape the library takes by
+                                       itself for launches of at most 2048 such tiles (DIRT_FLAG_TILES_LARGE alone pins four
+                                       waves per tile); where that shape does not exist -- meshes of more than 16 384 faces,
+                                       channel counts other than 1, 3, 4, the visibility pass -- the pair means 32x32. */
 #define DIRT_FLAG_GRAD_ROWS 0x1000u  /* pin the gradient kernel's face-loop shape instead of letting the library choose by
                                         frame size: every 8x8 block of a wave walks its own faces ... */
 #define DIRT_FLAG_GRAD_PAIRS 0x2000u /* ... or pairs of blocks share a face (fewer float atomics).  Results agree to

@@ -36,7 +36,7 @@ def run(budget=None, max_cases=None, seed=0, hard=False, max_dim=None, failures=
             s = scenes.rand_scene(int(rng.integers(1, 4000)), H, W, C, seed_, 0.001, 0.02)
         else:
             s = scenes.rand_scene(int(rng.integers(1, 3000)), H, W, C, seed_, float(rng.uniform(0.005, 0.1)), float(rng.uniform(0.1, 0.8)), kind == 'shared')
-        flags = int(rng.choice([0, 0x200, 0x400])) | int(rng.choice([0, 1])) | int(rng.choice([0, 0x1000, 0x2000, 0x4000, 0x8000, 0x8000, 0x10000]))
+        flags = int(rng.choice([0, 0x200, 0x400, 0x600])) | int(rng.choice([0, 1])) | int(rng.choice([0, 0x1000, 0x2000, 0x4000, 0x8000, 0x8000, 0x10000]))
         b = {k: v[None] for k, v in s.items() if isinstance(v, np.ndarray)}
         if kind in ('split', 'shared') and rng.random() < 0.4:  # a batch of scenes of the same sizes
             B = int(rng.integers(2, 4))

@@ -534,7 +534,8 @@ def test_library_picks_the_fastest_kernel_shape(gpu, config):
         grad_sets += [('px2', _lib.FLAG_GRAD_PX2), ('small', _lib.FLAG_GRAD_SMALL)]
     if C == 4:
         grad_sets += [('stream', _lib.FLAG_GRAD_STREAM)]
-    tile_sets = [('auto', 0), ('large', _lib.FLAG_TILES_LARGE), ('small', _lib.FLAG_TILES_SMALL)]
+    tile_sets = [('auto', 0), ('large', _lib.FLAG_TILES_LARGE), ('small', _lib.FLAG_TILES_SMALL),
+                 ('large8', _lib.FLAG_TILES_LARGE | _lib.FLAG_TILES_SMALL)]   # (both bits: 32 x 32 tiles, eight half-size waves each)
     for attempt in range(2):
         g = _time_shapes(config, gpu, grad_sets)
         r = _time_shapes(config, gpu, tile_sets)

@@ -33,7 +33,7 @@ def _fwd_gpu(s, dev, flags=0):
 # (the tile-shape flags of the forward kernels, each with one of the gradient kernel's face-loop shapes pinned as well)
 TILE_SHAPES = [pytest.param(0, id='auto'), pytest.param(0x200 | 0x2000, id='large-tiles'), pytest.param(0x400 | 0x1000, id='small-tiles'),
                pytest.param(0x400 | 0x4000, id='small-tiles-px1'), pytest.param(0x200 | 0x8000, id='large-tiles-px2'),
-               pytest.param(0x10000, id='px4')]
+               pytest.param(0x10000, id='px4'), pytest.param(0x600 | 0x2000, id='large-tiles-eight-waves')]
 
 
 def _assert_grad_close(got, ow, key, what, index=None):
